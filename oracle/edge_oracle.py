@@ -1,0 +1,591 @@
+"""CPU oracle for EDGE's degree-guided binomial diffusion hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under `graph-generation-edge_amd/` may import
+this file; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg use it, and there only as the checker / reported baseline.
+
+This is a dense-semantics restatement (torch CPU, fp32) of the reference
+algorithm.  Every function cites the reference file:line (relative to the
+reference tree) it follows.  It keeps the reference's data model on purpose
+(log-one-hot state `[P,2]`, `full_edge_index` `[2,P]`), so that it can be
+checked op-for-op against the reference itself; it is O(P) per step and only
+meant for sizes that finish in seconds.
+
+Pinning: `tests/golden/make_golden.py` imports the reference's own
+`diffusion/*.py` and `layers/layers.py` (with in-memory stand-ins for the
+absent `torch_scatter` / `torch_geometric` / `prettytable`), replays supplied
+uniforms through a patched `torch.rand_like`, and asserts this oracle equals
+the reference bit-for-bit on the diffusion functions and to 1e-6 on the GNN.
+The one piece with no source in the reference tree is PyG's `TransformerConv`
+(SURVEY.md App. B): `transformer_conv` below restates PyG's documented
+behaviour and is "parity unpinned" against PyG itself.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOG_ZERO_CLAMP = 1e-30   # diffusion_base.py:69
+CE_CONST = 6.9078e-29    # diffusion_binomial_active.py:176-177
+
+
+# --------------------------------------------------------------------------
+# uniforms
+# --------------------------------------------------------------------------
+class UniformTape:
+    """Hands out supplied uniforms in consumption order.
+
+    `chunks` is a list of fp32 arrays; each `take(shape)` pops the next one and
+    checks its shape.  This replaces the reference's `torch.rand_like`
+    (diffusion_base.py:176)."""
+
+    def __init__(self, chunks):
+        self.chunks = [torch.as_tensor(c, dtype=torch.float32) for c in chunks]
+        self.pos = 0
+
+    def take(self, shape):
+        u = self.chunks[self.pos]
+        self.pos += 1
+        assert tuple(u.shape) == tuple(shape), (tuple(u.shape), tuple(shape))
+        return u
+
+
+class CallbackTape:
+    """Uniform source backed by a callback `fn(tag, shape) -> fp32 tensor`."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.tag = None
+
+    def take(self, shape):
+        return self.fn(self.tag, shape)
+
+
+# --------------------------------------------------------------------------
+# a1: schedules and buffers
+# --------------------------------------------------------------------------
+def linear_alphas(T):
+    """diffusion_base.py:84-88."""
+    scale = 1000 / T
+    return 1 - torch.linspace(scale * 0.0001, scale * 0.02, T, dtype=torch.float64).numpy()
+
+
+def cosine_alphas(T, s=0.008):
+    """diffusion_base.py:91-107."""
+    steps = T + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    a = np.clip(ac[1:] / ac[:-1], a_min=0.001, a_max=1.)
+    return np.sqrt(a)
+
+
+def tt1_alphas(T):
+    """diffusion_base.py:110-111."""
+    return 1 / torch.linspace(1 + 1e-8, T + 1e-8, T, dtype=torch.float64).flip(0).numpy()
+
+
+SCHEDULES = {'linear': linear_alphas, 'cosine': cosine_alphas, 'Tt1': tt1_alphas}
+
+
+def log_1_min_a(a):
+    """diffusion_base.py:27-28 (1e-40 is an fp32 denormal)."""
+    return torch.log(1 - a.exp() + 1e-40)
+
+
+def log_add_exp(a, b):
+    """diffusion_base.py:31-33."""
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+def make_schedule(T, kind='linear', final_prob_edge=(1 - 1e-12, 1e-12), final_prob_node=(1 - 1e-12, 1e-12)):
+    """diffusion_binomial_vanilla.py:21-45: fp64 tables cast to fp32."""
+    alphas = torch.tensor(SCHEDULES[kind](T).astype('float64'))
+    log_alpha = torch.from_numpy(np.log(alphas.numpy()))
+    log_cumprod_alpha = torch.from_numpy(np.cumsum(log_alpha.numpy()))
+    s = SimpleNamespace()
+    s.T = T
+    s.log_alpha = log_alpha.float()
+    s.log_1_min_alpha = log_1_min_a(log_alpha).float()
+    s.log_cumprod_alpha = log_cumprod_alpha.float()
+    s.log_1_min_cumprod_alpha = log_1_min_a(log_cumprod_alpha).float()
+    s.log_final_prob_node = torch.tensor(list(final_prob_node))[None, :].log().float()
+    s.log_final_prob_edge = torch.tensor(list(final_prob_edge))[None, :].log().float()
+    return s
+
+
+def extract(a, t, ndim):
+    """diffusion_base.py:45-48."""
+    out = a.gather(-1, t)
+    return out.reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+
+# --------------------------------------------------------------------------
+# a2, a3: log-one-hot and Gumbel-argmax sampling
+# --------------------------------------------------------------------------
+def index_to_log_onehot(x, num_classes=2):
+    """diffusion_base.py:60-71."""
+    return torch.log(F.one_hot(x, num_classes).float().clamp(min=LOG_ZERO_CLAMP))
+
+
+def gumbel(u):
+    """diffusion_base.py:177."""
+    return -torch.log(-torch.log(u + 1e-30) + 1e-30)
+
+
+def sample_categorical_index(logits, u):
+    """diffusion_base.py:175-178 (argmax, ties -> class 0)."""
+    return (gumbel(u) + logits).argmax(dim=1)
+
+
+def log_sample_categorical(logits, tape, num_classes=2):
+    """diffusion_base.py:175-180."""
+    return index_to_log_onehot(sample_categorical_index(logits, tape.take(logits.shape)), num_classes)
+
+
+# --------------------------------------------------------------------------
+# dense batch (input layout of the path: datasets/data_utils.py:43-75,120-142)
+# --------------------------------------------------------------------------
+def make_batch(graphs, degree_dtype=torch.float32):
+    """graphs: list of dicts {n, edges (E,2) int with i<j or None, degree (n,) or None}.
+
+    Builds the fields the path reads: full_edge_index in
+    `torch.triu_indices(n, n, 1)` order with global node ids, full_edge_attr,
+    node_attr, degree, batch, nodes_per_graph, edges_per_graph."""
+    rows, cols, attrs, degs, bvec, npg, epg = [], [], [], [], [], [], []
+    off = 0
+    for b, g in enumerate(graphs):
+        n = int(g['n'])
+        r, c = torch.triu_indices(n, n, 1)
+        adj = torch.zeros(n, n, dtype=torch.long)
+        e = g.get('edges')
+        if e is not None and len(e):
+            e = torch.as_tensor(np.asarray(e), dtype=torch.long)
+            adj[e[:, 0], e[:, 1]] = 1
+            adj[e[:, 1], e[:, 0]] = 1
+        attrs.append(adj[r, c])
+        rows.append(r + off)
+        cols.append(c + off)
+        d = g.get('degree')
+        if d is None:
+            d = adj.sum(1)
+        degs.append(torch.as_tensor(np.asarray(d)).to(degree_dtype))
+        bvec.append(torch.full((n,), b, dtype=torch.long))
+        npg.append(n)
+        epg.append(n * (n - 1) // 2)
+        off += n
+    bt = SimpleNamespace()
+    bt.full_edge_index = torch.stack([torch.cat(rows), torch.cat(cols)])
+    bt.full_edge_attr = torch.cat(attrs)
+    bt.node_attr = torch.zeros(off, dtype=torch.long)
+    bt.degree = torch.cat(degs)
+    bt.batch = torch.cat(bvec)
+    bt.nodes_per_graph = torch.tensor(npg)
+    bt.edges_per_graph = torch.tensor(epg)
+    bt.num_nodes = off
+    bt.num_graphs = len(graphs)
+    return bt
+
+
+def scatter_sum(src, index, dim_size):
+    """torch_scatter.scatter(reduce='sum') along dim 0 / -1 for 1-D or 2-D src."""
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+def scatter_mean(src, index, dim_size):
+    """torch_scatter.scatter(reduce='mean', dim=0): sum / clamp(count, 1)."""
+    out = scatter_sum(src, index, dim_size)
+    cnt = scatter_sum(torch.ones(index.shape[0], dtype=src.dtype), index, dim_size).clamp(min=1)
+    return out / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+
+# --------------------------------------------------------------------------
+# a4-a7: forward noising
+# --------------------------------------------------------------------------
+def q_pred(sched, log_x0, t, log_final_prob):
+    """diffusion_binomial_vanilla.py:272-288 (one of node / edge)."""
+    la = extract(sched.log_cumprod_alpha, t, 2)
+    l1a = extract(sched.log_1_min_cumprod_alpha, t, 2)
+    return log_add_exp(log_x0 + la, l1a + log_final_prob)
+
+
+def q_pred_one_timestep(sched, log_xtm1, t, log_final_prob):
+    """diffusion_binomial_vanilla.py:226-243."""
+    la = extract(sched.log_alpha, t, 2)
+    l1a = extract(sched.log_1_min_alpha, t, 2)
+    return log_add_exp(log_xtm1 + la, l1a + log_final_prob)
+
+
+def q_sample(sched, bt, t_node, t_edge, tape):
+    """diffusion_base.py:154-163: node draw first, then edge draw."""
+    lpn = q_pred(sched, bt.log_node_attr, t_node, sched.log_final_prob_node)
+    lpe = q_pred(sched, bt.log_full_edge_attr, t_edge, sched.log_final_prob_edge)
+    return log_sample_categorical(lpn, tape), log_sample_categorical(lpe, tape)
+
+
+def q_sample_and_set_xtmin1_xt_given_x0(sched, bt, t_node, t_edge, tape):
+    """diffusion_binomial_vanilla.py:192-212."""
+    bt.log_node_attr = index_to_log_onehot(bt.node_attr)
+    bt.log_full_edge_attr = index_to_log_onehot(bt.full_edge_attr)
+    tm1n, tm1e = t_node - 1, t_edge - 1
+    tm1n_c = torch.where(tm1n < 0, torch.zeros_like(tm1n), tm1n)
+    tm1e_c = torch.where(tm1e < 0, torch.zeros_like(tm1e), tm1e)
+    ln, le = q_sample(sched, bt, tm1n_c, tm1e_c, tape)
+    ln[tm1n < 0] = bt.log_node_attr[tm1n < 0]
+    le[tm1e < 0] = bt.log_full_edge_attr[tm1e < 0]
+    bt.log_node_attr_tmin1, bt.log_full_edge_attr_tmin1 = ln, le
+    lpn = q_pred_one_timestep(sched, bt.log_node_attr_tmin1, t_node, sched.log_final_prob_node)
+    lpe = q_pred_one_timestep(sched, bt.log_full_edge_attr_tmin1, t_edge, sched.log_final_prob_edge)
+    bt.log_node_attr_t = log_sample_categorical(lpn, tape)
+    bt.log_full_edge_attr_t = log_sample_categorical(lpe, tape)
+
+
+def prepare_data_for_sampling(sched, bt, tape):
+    """diffusion_binomial_vanilla.py:303-316: x_T ~ prior."""
+    bt.log_node_attr = index_to_log_onehot(bt.node_attr)
+    lpn = torch.ones_like(bt.log_node_attr) * sched.log_final_prob_node
+    bt.log_node_attr_t = log_sample_categorical(lpn, tape)
+    bt.log_full_edge_attr = index_to_log_onehot(bt.full_edge_attr)
+    lpe = torch.ones_like(bt.log_full_edge_attr) * sched.log_final_prob_edge
+    bt.log_full_edge_attr_t = log_sample_categorical(lpe, tape)
+    return bt
+
+
+# --------------------------------------------------------------------------
+# a8-a11: degrees and active sets
+# --------------------------------------------------------------------------
+def compute_degree(bits, full_edge_index, num_nodes):
+    """diffusion_binomial_active.py:92-95."""
+    return scatter_sum(bits, full_edge_index[0], num_nodes) + scatter_sum(bits, full_edge_index[1], num_nodes)
+
+
+def q_posterior_actives(sched, degree_start, degree_t, t_node):
+    """diffusion_binomial_active.py:97-119 (op order of SURVEY App. A3)."""
+    tm1 = t_node - 1
+    tm1 = torch.where(tm1 < 0, torch.zeros_like(tm1), tm1)
+    log_beta_t = extract(sched.log_1_min_alpha, t_node, 1)
+    lca_tm1 = extract(sched.log_cumprod_alpha, tm1, 1)
+    l1ca_t = extract(sched.log_1_min_cumprod_alpha, t_node, 1)
+    logprob = log_beta_t + lca_tm1 - l1ca_t
+    logit = logprob - log_1_min_a(logprob)
+    n_trials = torch.max(degree_start - degree_t, torch.zeros_like(degree_start))
+    nochange = torch.distributions.Binomial(total_count=n_trials, logits=logit).log_prob(
+        torch.zeros_like(degree_start))
+    change = log_1_min_a(nochange)
+    un = torch.stack([nochange, change], dim=1)
+    return un - un.logsumexp(1, keepdim=True)
+
+
+def active_pairs_from_mask(bt, mask):
+    """diffusion_binomial_active.py:126-128 / 140-145."""
+    nodes = mask.nonzero(as_tuple=True)[0]
+    emask = mask[bt.full_edge_index[0]].logical_and(mask[bt.full_edge_index[1]])
+    return nodes, emask.nonzero(as_tuple=True)[0], emask
+
+
+def p_sample_and_set_actives(sched, bt, t_node, tape):
+    """diffusion_binomial_active.py:121-128."""
+    bt.degree_t = compute_degree(bt.log_full_edge_attr_t.argmax(1), bt.full_edge_index, bt.num_nodes)
+    lp = q_posterior_actives(sched, bt.degree, bt.degree_t, t_node)
+    mask = log_sample_categorical(lp, tape).argmax(1).bool()
+    bt.active_node_indices, bt.active_edge_indices, _ = active_pairs_from_mask(bt, mask)
+    return lp
+
+
+def q_set_actives(bt):
+    """diffusion_binomial_active.py:134-145."""
+    bt.degree_tmin1 = compute_degree(bt.log_full_edge_attr_tmin1.argmax(1), bt.full_edge_index, bt.num_nodes)
+    bt.degree_t = compute_degree(bt.log_full_edge_attr_t.argmax(1), bt.full_edge_index, bt.num_nodes)
+    mask = bt.degree_tmin1 > bt.degree_t
+    bt.active_node_indices, bt.active_edge_indices, bt.edge_predict_masks = active_pairs_from_mask(bt, mask)
+
+
+# --------------------------------------------------------------------------
+# a12-a15: the denoising network TGNN_degree_guided
+# --------------------------------------------------------------------------
+def tgnn_param_shapes(dim=64, num_heads=(8, 8, 8, 8, 1), num_classes=2):
+    """state_dict names/shapes of TGNN_degree_guided (layers.py:250-313)."""
+    d = dim
+    s = {}
+    s['embedding_t.weight'] = (d, 1); s['embedding_t.bias'] = (d,)
+    s['embedding_0.weight'] = (d, 1); s['embedding_0.bias'] = (d,)
+    s['embedding_sel.weight'] = (2, d)
+    s['node_in.0.weight'] = (d, 3 * d); s['node_in.0.bias'] = (d,)
+    for name, din in (('global_mlp', d), ('context_mlp', 2 * d), ('mlp', d)):
+        s[f'{name}.0.weight'] = (4 * d, din); s[f'{name}.0.bias'] = (4 * d,)
+        s[f'{name}.2.weight'] = (d, 4 * d); s[f'{name}.2.bias'] = (d,)
+    s['gru.weight_ih_l0'] = (3 * d, d); s['gru.weight_hh_l0'] = (3 * d, d)
+    s['gru.bias_ih_l0'] = (3 * d,); s['gru.bias_hh_l0'] = (3 * d,)
+    for i, h in enumerate(num_heads):
+        s[f'layers.time{i}.linear.weight'] = (d, d); s[f'layers.time{i}.linear.bias'] = (d,)
+        for nm in ('key', 'query', 'value'):
+            s[f'layers.conv{i}.lin_{nm}.weight'] = (h * d, 2 * d); s[f'layers.conv{i}.lin_{nm}.bias'] = (h * d,)
+        s[f'layers.conv{i}.lin_skip.weight'] = (d, 2 * d); s[f'layers.conv{i}.lin_skip.bias'] = (d,)
+    s['dummy_edge_feats'] = (d,)
+    s['node_out_mlp.0.weight'] = (2 * d, 4 * d); s['node_out_mlp.0.bias'] = (2 * d,)
+    s['node_out_mlp.2.weight'] = (2 * d, 2 * d); s['node_out_mlp.2.bias'] = (2 * d,)
+    s['node_out_mlp.4.weight'] = (2 * d, 2 * d); s['node_out_mlp.4.bias'] = (2 * d,)
+    s['final_out.0.weight'] = (2 * d, 2 * d); s['final_out.0.bias'] = (2 * d,)
+    s['final_out.2.weight'] = (d, 2 * d); s['final_out.2.bias'] = (d,)
+    s['final_out.4.weight'] = (num_classes, d); s['final_out.4.bias'] = (num_classes,)
+    return s
+
+
+def random_tgnn_params(seed, dim=64, num_heads=(8, 8, 8, 8, 1), scale=None):
+    """Deterministic synthetic weights (numpy PCG64), fan-in scaled; fixtures store only the seed."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in tgnn_param_shapes(dim, num_heads).items():
+        fan_in = shp[-1] if len(shp) > 1 else dim
+        sc = (1.0 / math.sqrt(fan_in)) if scale is None else scale
+        out[name] = torch.from_numpy((rng.standard_normal(shp) * sc).astype(np.float32))
+    return out
+
+
+def sinusoidal_pos_emb(t, dim, num_steps, rescale_steps=4000.0):
+    """layers.py:45-60."""
+    x = t / float(num_steps) * float(rescale_steps)
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    emb = torch.exp(torch.arange(half) * -emb)
+    emb = x[:, None] * emb[None, :]
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+def mish(x):
+    """layers.py:40-42."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def transformer_conv(x, edge_index, Wq, bq, Wk, bk, Wv, bv, Ws, bs, heads, out_ch):
+    """PyG TransformerConv(concat=False, root_weight=True, beta=False), SURVEY App. B.
+
+    Messages flow edge_index[0] (source j) -> edge_index[1] (target i).
+    Source not in the reference tree: parity unpinned against PyG."""
+    N = x.shape[0]
+    q = F.linear(x, Wq, bq).view(N, heads, out_ch)
+    k = F.linear(x, Wk, bk).view(N, heads, out_ch)
+    v = F.linear(x, Wv, bv).view(N, heads, out_ch)
+    src, dst = edge_index[0], edge_index[1]
+    a = (q[dst] * k[src]).sum(-1) / math.sqrt(out_ch)               # [E, heads]
+    amax = torch.full((N, heads), float('-inf')).scatter_reduce(
+        0, dst[:, None].expand(-1, heads), a, reduce='amax', include_self=True)
+    w = (a - amax[dst]).exp()
+    denom = scatter_sum(w, dst, N)
+    alpha = w / (denom[dst] + 1e-16)
+    out = scatter_sum(v[src] * alpha[:, :, None], dst, N)           # [N, heads, C]
+    out = out.mean(dim=1)
+    return out + F.linear(x, Ws, bs)
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRU(dim, dim), one step (layers.py:289,360): gates ordered (r, z, n)."""
+    gi = F.linear(x, w_ih, b_ih)
+    gh = F.linear(h, w_hh, b_hh)
+    i_r, i_z, i_n = gi.chunk(3, 1)
+    h_r, h_z, h_n = gh.chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def _mlp2(p, name, x):
+    return F.linear(F.silu(F.linear(x, p[f'{name}.0.weight'], p[f'{name}.0.bias'])),
+                    p[f'{name}.2.weight'], p[f'{name}.2.bias'])
+
+
+def tgnn_forward(p, bt, t_node, max_degree, num_steps, num_heads=(8, 8, 8, 8, 1), dim=64,
+                 return_intermediates=False):
+    """TGNN_degree_guided.forward, eval mode / dropout 0 (layers.py:315-383).
+
+    Returns edge logits [A,2] for bt.active_edge_indices (row k <-> k-th active pair)."""
+    bits = bt.log_full_edge_attr_t.argmax(-1)
+    is_edge = bits.nonzero(as_tuple=True)[0]
+    ei = bt.full_edge_index[:, is_edge]
+    ei = torch.cat([ei, ei.flip(0)], dim=-1)                                        # :323-324
+    N = bt.num_nodes
+    deg = torch.zeros(N).index_add_(0, ei[0], torch.ones(ei.shape[1]))              # pyg.utils.degree
+    nodes_t = deg.clamp(max=max_degree + 1).long()                                  # :326
+    sel = torch.zeros_like(nodes_t)
+    nodes_t = nodes_t[..., None] / max_degree                                       # :330
+    nodes_0 = bt.degree[..., None] / max_degree                                     # :331
+    sel[bt.active_node_indices] = 1
+    e_t = F.linear(nodes_t, p['embedding_t.weight'], p['embedding_t.bias'])
+    e_0 = F.linear(nodes_0, p['embedding_0.weight'], p['embedding_0.bias'])
+    e_s = F.embedding(sel, p['embedding_sel.weight'])
+    nodes = F.silu(F.linear(torch.cat([e_t, e_0, e_s], -1), p['node_in.0.weight'], p['node_in.0.bias']))
+    t = _mlp2(p, 'mlp', sinusoidal_pos_emb(t_node, dim, num_steps))                 # :338-339
+    h = nodes
+    ctx = _mlp2(p, 'global_mlp', scatter_mean(nodes, bt.batch, bt.num_graphs))      # :342-343
+    ctx = ctx.repeat_interleave(bt.nodes_per_graph, dim=0)
+    inter = {'nodes_in': nodes.clone()}
+    for i, nh in enumerate(num_heads):
+        t_emb = F.linear(mish(t), p[f'layers.time{i}.linear.weight'], p[f'layers.time{i}.linear.bias'])
+        x = torch.cat([nodes, t_emb], -1)
+        c = f'layers.conv{i}.lin_'
+        x = transformer_conv(x, ei, p[c + 'query.weight'], p[c + 'query.bias'], p[c + 'key.weight'],
+                             p[c + 'key.bias'], p[c + 'value.weight'], p[c + 'value.bias'],
+                             p[c + 'skip.weight'], p[c + 'skip.bias'], nh, dim)
+        x = F.silu(x)                                                               # norm 'None' = identity
+        h = gru_cell(x, h, p['gru.weight_ih_l0'], p['gru.weight_hh_l0'], p['gru.bias_ih_l0'], p['gru.bias_hh_l0'])
+        nodes = h
+        nctx = _mlp2(p, 'context_mlp', torch.cat([nodes, ctx], -1))                 # :366
+        ctx = _mlp2(p, 'global_mlp', scatter_mean(ctx + nctx, bt.batch, bt.num_graphs))
+        ctx = ctx.repeat_interleave(bt.nodes_per_graph, dim=0)
+        nodes = nodes + ctx                                                         # :371
+        inter[f'h{i}'] = h.clone()
+        inter[f'nodes{i}'] = nodes.clone()
+    row = bt.full_edge_index[0].index_select(0, bt.active_edge_indices)
+    col = bt.full_edge_index[1].index_select(0, bt.active_edge_indices)
+    z = torch.cat([nodes, e_t, e_0, e_s], -1)                                       # :377
+    z = F.linear(z, p['node_out_mlp.0.weight'], p['node_out_mlp.0.bias'])
+    z = F.linear(F.silu(z), p['node_out_mlp.2.weight'], p['node_out_mlp.2.bias'])
+    z = F.linear(F.silu(z), p['node_out_mlp.4.weight'], p['node_out_mlp.4.bias'])
+    e = z[row] + z[col]                                                             # :380
+    e = F.linear(e, p['final_out.0.weight'], p['final_out.0.bias'])
+    e = F.linear(F.silu(e), p['final_out.2.weight'], p['final_out.2.bias'])
+    e = F.linear(F.silu(e), p['final_out.4.weight'], p['final_out.4.bias'])
+    if return_intermediates:
+        inter['node_out'] = z
+        return e, inter
+    return e
+
+
+# --------------------------------------------------------------------------
+# a16, a17: reverse step and the sampling loop
+# --------------------------------------------------------------------------
+class EdgeOracle:
+    """Counterpart of BinomialDiffusionActive + TGNN_degree_guided for the
+    `xt_prescribed_st` / `vb_ce_xt_prescribred_st` path."""
+
+    def __init__(self, params, T, max_degree, num_heads=(8, 8, 8, 8, 1), dim=64, schedule='linear',
+                 final_prob_edge=(1 - 1e-12, 1e-12)):
+        self.p = params
+        self.T = T
+        self.max_degree = max_degree
+        self.num_heads = tuple(num_heads)
+        self.dim = dim
+        self.sched = make_schedule(T, schedule, final_prob_edge)
+        self.Lt_history = torch.zeros(T)
+        self.Lt_count = torch.zeros(T)
+        self.logit_override = None   # optional callable(step_t, bt) -> logits, for tie-free trajectory checks
+
+    def denoise(self, bt, t_node):
+        return tgnn_forward(self.p, bt, t_node, self.max_degree, self.T, self.num_heads, self.dim)
+
+    def p_sample(self, bt, t_node, tape, record=None):
+        """diffusion_binomial_active.py:72-90."""
+        lp_active = p_sample_and_set_actives(self.sched, bt, t_node, tape)
+        if record is not None:
+            record['degree_t'] = bt.degree_t.clone()
+            record['active_node_indices'] = bt.active_node_indices.clone()
+            record['active_edge_indices'] = bt.active_edge_indices.clone()
+        if bt.active_edge_indices.size(0) == 0:
+            return bt.log_node_attr_t, bt.log_full_edge_attr_t
+        if self.logit_override is not None:
+            logits = self.logit_override(int(t_node[0]), bt)
+        else:
+            logits = self.denoise(bt, t_node)
+        log_pred_node = F.log_softmax(bt.log_node_attr, dim=1)          # :153, layers.py:383 passthrough
+        log_pred_edge = F.log_softmax(logits, dim=1)
+        out_node = log_sample_categorical(log_pred_node, tape)
+        out_edge_active = log_sample_categorical(log_pred_edge, tape)
+        out_edge = bt.log_full_edge_attr_t
+        out_edge[bt.active_edge_indices] = out_edge_active
+        if record is not None:
+            record['logits'] = logits.clone()
+            record['sampled_bits'] = out_edge_active.argmax(1).clone()
+        return out_node, out_edge
+
+    def sample(self, bt, tape, record=None):
+        """diffusion_base.py:190-230 (bt comes from the empty-graph sampler)."""
+        prepare_data_for_sampling(self.sched, bt, tape)
+        for t in reversed(range(self.T)):
+            t_node = torch.full((bt.num_nodes,), t, dtype=torch.long)
+            rec = {} if record is not None else None
+            ln, le = self.p_sample(bt, t_node, tape, rec)
+            bt.log_full_edge_attr_t, bt.log_node_attr_t = le, ln
+            if record is not None:
+                record[t] = rec
+        bits = bt.log_full_edge_attr_t.argmax(-1)
+        is_edge = bits.nonzero(as_tuple=True)[0]
+        bt.edge_index = bt.full_edge_index[:, is_edge]
+        bt.edge_attr = bits[is_edge]
+        bt.node_attr_out = bt.log_node_attr_t.argmax(-1)
+        es = scatter_sum(torch.ones_like(bt.edge_index[0]), bt.batch[bt.edge_index[0]], bt.num_graphs)
+        bt.edge_slice = torch.cumsum(F.pad(es, (1, 0), 'constant', 0), 0)
+        return bt
+
+    # ----------------------------------------------------------------------
+    # a18-a22: losses
+    # ----------------------------------------------------------------------
+    def compute_MC_KL_joint(self, bt, t_node):
+        """diffusion_binomial_active.py:157-181."""
+        logits = self.denoise(bt, t_node)
+        lp = F.log_softmax(logits, dim=1)
+        tgt = bt.log_full_edge_attr_tmin1.index_select(0, bt.active_edge_indices)
+        ce = -(tgt.exp() * lp).sum(dim=1)
+        gidx = bt.batch[bt.full_edge_index[0].index_select(0, bt.active_edge_indices)]
+        ce = scatter_sum(ce, gidx, bt.num_graphs)
+        n_act = scatter_sum(torch.ones_like(bt.active_edge_indices), gidx, bt.num_graphs)
+        nn_ = scatter_sum(torch.ones(bt.num_nodes), bt.batch, bt.num_graphs)
+        n_inact = nn_ * (nn_ - 1) // 2 - n_act
+        ce = ce + CE_CONST * n_inact
+        return ce + CE_CONST * bt.edges_per_graph, logits
+
+    def kl_prior(self, bt):
+        """diffusion_binomial_vanilla.py:116-136."""
+        s = self.sched
+        tn = (self.T - 1) * torch.ones(bt.num_nodes).long()
+        te = (self.T - 1) * torch.ones(int(bt.edges_per_graph.sum())).long()
+        qn = q_pred(s, bt.log_node_attr, tn, s.log_final_prob_node)
+        qe = q_pred(s, bt.log_full_edge_attr, te, s.log_final_prob_edge)
+        fn = s.log_final_prob_node * torch.ones_like(qn)
+        fe = s.log_final_prob_edge * torch.ones_like(qe)
+        kn = (qn.exp() * (qn - fn)).sum(dim=1)
+        ke = (qe.exp() * (qe - fe)).sum(dim=1)
+        return scatter_sum(kn, bt.batch, bt.num_graphs) + \
+            scatter_sum(ke, bt.batch[bt.full_edge_index[0]], bt.num_graphs)
+
+    def sample_time(self, b, method='importance', generator=None):
+        """diffusion_binomial_vanilla.py:248-269."""
+        if method == 'importance':
+            if not (self.Lt_count > 10).all():
+                return self.sample_time(b, 'uniform', generator)
+            Lt_sqrt = torch.sqrt(self.Lt_history + 1e-10) + 0.0001
+            Lt_sqrt[0] = Lt_sqrt[1]
+            pt_all = Lt_sqrt / Lt_sqrt.sum()
+            t = torch.multinomial(pt_all, num_samples=b, replacement=True, generator=generator)
+            return t, pt_all.gather(dim=0, index=t)
+        t = torch.randint(0, self.T, (b,), generator=generator).long()
+        return t, torch.ones_like(t).float() / self.T
+
+    def loss(self, bt, t, pt, tape, training=True, record=None):
+        """_train_loss / _eval_loss for 'vb_ce_xt_prescribred_st'
+        (diffusion_binomial_active.py:228-264 / 195-226). Returns -vb_loss [B]."""
+        t_node = t.repeat_interleave(bt.nodes_per_graph)
+        t_edge = t.repeat_interleave(bt.edges_per_graph)
+        q_sample_and_set_xtmin1_xt_given_x0(self.sched, bt, t_node, t_edge, tape)
+        q_set_actives(bt)
+        kl, logits = self.compute_MC_KL_joint(bt, t_node)
+        if training:
+            Lt2 = kl.pow(2)
+            prev = self.Lt_history.gather(dim=0, index=t)
+            self.Lt_history.scatter_(dim=0, index=t, src=(0.1 * Lt2 + 0.9 * prev).detach())
+            self.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(Lt2))
+        prior = self.kl_prior(bt)
+        vb = kl / pt + prior
+        bt.num_entries = bt.full_edge_attr.shape[0]
+        if record is not None:
+            record.update(kl=kl.clone(), kl_prior=prior.clone(), logits=logits.clone())
+        return -vb
+
+
+def elbo_bpd(neg_vb, num_entries):
+    """diffusion/loss.py:10-12."""
+    return -neg_vb.sum() / (math.log(2) * num_entries)

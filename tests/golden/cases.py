@@ -1,0 +1,66 @@
+"""Seeded inputs shared by the golden-vector generator and the parity tests.
+
+Only inputs that can be regenerated from a seed live here (graphs, weights,
+uniforms); the expected OUTPUTS are what `make_golden.py` stores as `.npz`.
+Uniforms are drawn on the 2^-24 grid that `torch.rand` (CPU, fp32) emits.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, 'graph-generation-edge_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from edgehip import synth  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+HEADS = (8, 8, 8, 8, 1)
+DIM = 64
+
+
+def uniforms(rng, *shape):
+    return torch.from_numpy((rng.integers(0, 1 << 24, size=shape).astype(np.float32) * np.float32(2.0 ** -24)))
+
+
+def random_graph(rng, n, p):
+    iu, ju = np.triu_indices(n, 1)
+    keep = rng.random(len(iu)) < p
+    return np.stack([iu[keep], ju[keep]], axis=1).astype(np.int64)
+
+
+def toy_graphs(seed=11):
+    """Two small graphs (n=7, n=9) - the 2-graph toy batch of SURVEY §8c."""
+    rng = np.random.default_rng(seed)
+    return [dict(n=7, edges=random_graph(rng, 7, 0.5)), dict(n=9, edges=random_graph(rng, 9, 0.45))]
+
+
+def ragged_graphs(seed=12):
+    """Ragged batch incl. a 1-node graph (no pairs), a 2-node graph and an empty graph."""
+    rng = np.random.default_rng(seed)
+    return [dict(n=1, edges=np.zeros((0, 2), np.int64)),
+            dict(n=12, edges=random_graph(rng, 12, 0.4)),
+            dict(n=2, edges=np.array([[0, 1]], np.int64)),
+            dict(n=33, edges=random_graph(rng, 33, 0.2)),
+            dict(n=5, edges=np.zeros((0, 2), np.int64)),
+            dict(n=70, edges=random_graph(rng, 70, 0.15))]
+
+
+def polblogs_graph(seed=0):
+    n, e = synth.polblogs_like(seed)
+    return [dict(n=n, edges=e)]
+
+
+def max_degree_of(graphs):
+    return int(max(synth.degrees(g['n'], g['edges']).max() if len(g['edges']) else 0 for g in graphs))
+
+
+CASES = {
+    # name: (graph builder, T, weight seed, uniform seed)
+    'toy': (toy_graphs, 32, 101, 201),
+    'ragged': (ragged_graphs, 48, 102, 202),
+    'polblogs1': (polblogs_graph, 512, 103, 203),
+}
