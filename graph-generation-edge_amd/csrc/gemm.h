@@ -1,0 +1,59 @@
+// gemm.h - fp32 MFMA building blocks (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+//
+// Operand scheme.  One wave owns a 32-row x 32-col output tile (16 accumulator registers).  The
+// instruction sums over k in {0,1}: lanes 0-31 supply k=0, lanes 32-63 supply k=1.  Which PHYSICAL
+// k a lane feeds is free as long as A and B agree, so for a 64-deep chunk lane half h feeds
+// k = 32*h + s at step s (s = 0..31).  Each lane then needs 32 CONTIGUOUS floats of its A row and
+// of its W row (torch Linear stores W as [N,K], k contiguous): eight 16-byte loads, no LDS, no
+// transposes.  C layout: lane l holds column l&31, register r holds row (r&3) + 8*(r>>2) + 4*(l>>5).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct eh_frag { f32x4 v[8]; };   // 32 floats of one row, one k-half of a 64-deep chunk
+
+// p points at row_base + chunk_k0 + 32*half ; must be 16-byte aligned
+__device__ static inline void eh_load_frag(eh_frag& f, const float* __restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+}
+
+__device__ static inline void eh_mma64(f32x16& acc, const eh_frag& a, const eh_frag& b) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[i][c], b.v[i][c], acc, 0, 0, 0);
+    }
+}
+
+__device__ static inline int eh_crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+static inline __device__ f32x16 eh_zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+
+// Generic linear-layer descriptor (see gemm.hip)
+struct eh_gemm_desc {
+    const float* A; int lda;            // A rows, k < K1
+    const float* A2; int lda2; int K1;  // optional second source for k >= K1 (concat along K); K1 % 64 == 0
+    const float* W; int K; int N;       // W [N,K] row-major, K % 64 == 0, N % 32 == 0
+    const float* bias;                  // [N] or null
+    const float* gbias0;                // [B,ldg] per-graph bias or null
+    const float* gbias1;                // [B,ldg] per-graph bias applied where rowflag[row] > 0, or null
+    const int32_t* rowflag;
+    int ldg;
+    float* Y; int ldy; int act;         // act: 0 none, 1 SiLU
+    const int32_t* tile_graph;          // node tiling (one graph per tile) or null for plain 32-row tiles
+    const int32_t* tile_row0;
+    const int32_t* tile_rows;
+    int num_tiles;
+    int64_t M;                          // rows when tile_row0 == null
+    const int32_t* m_dev;               // optional device-side row count overriding M
+};
+
+int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream);

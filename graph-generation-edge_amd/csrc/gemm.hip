@@ -1,0 +1,97 @@
+// gemm.hip - generic fp32 MFMA linear layer: Y = act(A W^T + bias + per-graph bias).
+// Skinny-K (64..576), tall-M (one row per node) shapes: each wave keeps a 32-row A fragment in
+// registers and streams W rows from L2; see gemm.h for the operand scheme.
+#include "gemm.h"
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int nt_per_block) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    int row0, rows, g = 0;
+    if (d.tile_row0) {
+        if (tile >= d.num_tiles) return;
+        row0 = d.tile_row0[tile]; rows = d.tile_rows[tile]; g = d.tile_graph[tile];
+    } else {
+        int64_t M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
+        int64_t r0 = (int64_t)tile * 32;
+        if (r0 >= M) return;
+        row0 = (int)r0; rows = (int)((M - r0) < 32 ? (M - r0) : 32);
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t arow = row0 + (r < rows ? r : rows - 1);
+    const float* ap = d.A + arow * d.lda + hh * 32;
+    const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
+    const int nt_total = d.N >> 5;
+    const int nt0 = blockIdx.y * nt_per_block;
+    const int nt1 = (nt0 + nt_per_block < nt_total) ? nt0 + nt_per_block : nt_total;
+    for (int nt = nt0; nt < nt1; nt += NACC) {
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
+        for (int kc = 0; kc < d.K; kc += 64) {
+            eh_frag a;
+            eh_load_frag(a, (kc < d.K1) ? ap + kc : ap2 + (kc - d.K1));
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                if (nt + j < nt1) {
+                    eh_frag b;
+                    eh_load_frag(b, d.W + (int64_t)((nt + j) * 32 + r) * d.K + kc + hh * 32);
+                    eh_mma64(acc[j], a, b);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            if (nt + j < nt1) {
+                const int col = (nt + j) * 32 + r;
+                float add0 = d.bias ? d.bias[col] : 0.0f;
+                if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
+                const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int rr = eh_crow(i, lane);
+                    if (rr < rows) {
+                        int64_t grow = row0 + rr;
+                        float v = acc[j][i] + add0;
+                        if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
+                        if (d.act == 1) v = eh_silu(v);
+                        d.Y[grow * d.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
+    if (!d.A || !d.W || !d.Y) return EDGEHIP_ERR_ARG;
+    if (d.K <= 0 || d.N <= 0 || (d.K & 63) || (d.N & 31)) return EDGEHIP_ERR_UNSUPPORTED;
+    if (d.A2 ? ((d.K1 & 63) || d.K1 <= 0 || d.K1 >= d.K) : (d.K1 != d.K)) return EDGEHIP_ERR_ARG;
+    if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;
+    int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
+    if (tiles <= 0) return EDGEHIP_OK;
+    int gx = (int)((tiles + 3) / 4);
+    int nt_total = d.N >> 5;
+    const int nacc = nt_total >= 2 ? 2 : 1;
+    int max_split = nt_total / nacc;
+    int want = (2048 + gx - 1) / gx;
+    int split = want < 1 ? 1 : (want > max_split ? max_split : want);
+    int per = (nt_total + split - 1) / split;
+    per = ((per + nacc - 1) / nacc) * nacc;
+    split = (nt_total + per - 1) / per;
+    if (nacc == 2)
+        hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per);
+    else
+        hipLaunchKernelGGL(k_gemm<1>, dim3(gx, split), dim3(256), 0, stream, d, per);
+    if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+    return EDGEHIP_OK;
+}
+
+extern "C" int edgehip_linear_fwd(const float* X, int64_t M, int32_t K, const float* W, const float* bias, int32_t N,
+                                  int32_t act, float* Y, void* stream) {
+    EH_CHECK_ARG(X && W && Y && M >= 0);
+    if (M == 0) return EDGEHIP_OK;
+    eh_gemm_desc d = {};
+    d.A = X; d.lda = K; d.K1 = K; d.W = W; d.K = K; d.N = N; d.bias = bias; d.Y = Y; d.ldy = N; d.act = act; d.M = M;
+    return eh_launch_gemm(d, eh_stream(stream));
+}

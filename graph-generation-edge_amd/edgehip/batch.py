@@ -1,0 +1,167 @@
+"""GraphBatch: the native counterpart of the PyG `Batch` objects the reference path consumes.
+
+It carries the fields SURVEY.md section 8b lists (`degree`, `batch`, `nodes_per_graph`,
+`edges_per_graph`, `num_nodes`, `num_graphs`, and after sampling `edge_index`, `edge_attr`,
+`node_attr`, `_slice_dict['edge_index']`), but never materialises the O(n^2)
+`full_edge_index` / `full_edge_attr` (datasets/data_utils.py:53-56): the edge state lives in a
+symmetric bit matrix on the device (include/edgehip.h "State layout").
+`full_edge_index` / `full_edge_attr` are provided as lazy properties for small batches so that
+code written against the reference layout (tests, the oracle) can still read them.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+class GraphBatch:
+    def __init__(self, nodes_per_graph, degree=None, edges=None, device='cuda', gid_base=0, degree_dtype=None):
+        """nodes_per_graph: list[int]; degree: list of per-graph degree arrays (d0) or None;
+        edges: list of per-graph [E,2] local-id arrays (x0, training batches) or None."""
+        npg = np.asarray(nodes_per_graph, dtype=np.int64)
+        B = len(npg)
+        self.device = torch.device(device)
+        self.num_graphs = B
+        self.num_nodes = int(npg.sum())
+        node_ptr = np.zeros(B + 1, dtype=np.int64)
+        node_ptr[1:] = np.cumsum(npg)
+        stride = ((npg + 31) // 32 + 3) // 4 * 4
+        stride = np.maximum(stride, 4)
+        adj_ptr = np.zeros(B + 1, dtype=np.int64)
+        adj_ptr[1:] = np.cumsum(npg * stride)
+        pair_ptr = np.zeros(B + 1, dtype=np.int64)
+        pair_ptr[1:] = np.cumsum(npg * (npg - 1) // 2)
+        tiles = (npg + 31) // 32
+        tile_ptr = np.zeros(B + 1, dtype=np.int64)
+        tile_ptr[1:] = np.cumsum(tiles)
+        NT = int(tile_ptr[-1])
+        tile_graph = np.repeat(np.arange(B), tiles)
+        tile_local = np.arange(NT) - tile_ptr[tile_graph] if NT else np.zeros(0, np.int64)
+        tile_row0 = node_ptr[tile_graph] + tile_local * 32 if NT else np.zeros(0, np.int64)
+        tile_rows = np.minimum(32, npg[tile_graph] - tile_local * 32) if NT else np.zeros(0, np.int64)
+        node_graph = np.repeat(np.arange(B), npg)
+        self.host = SimpleNamespace(nodes_per_graph=npg, node_ptr=node_ptr, adj_stride=stride, adj_ptr=adj_ptr,
+                                    pair_ptr=pair_ptr, tile_ptr=tile_ptr)
+        self.adj_words = int(adj_ptr[-1])
+        self.num_tiles = NT
+        self.num_pairs = int(pair_ptr[-1])
+        dev = self.device
+
+        def i32(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+        def i64(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+        self._t = dict(node_ptr=i32(node_ptr), node_graph=i32(node_graph), adj_ptr=i64(adj_ptr),
+                       adj_stride=i32(stride), pair_ptr=i64(pair_ptr), tile_ptr=i32(tile_ptr),
+                       tile_graph=i32(tile_graph), tile_row0=i32(tile_row0), tile_rows=i32(tile_rows))
+        L = capi.Layout()
+        L.num_graphs, L.num_nodes, L.num_tiles = B, self.num_nodes, NT
+        L.max_nodes = int(npg.max()) if B else 0
+        L.gid_base = gid_base
+        for k, v in self._t.items():
+            setattr(L, k, v.data_ptr())
+        self.layout = L
+        # reference-named fields
+        self.nodes_per_graph = torch.from_numpy(npg).to(dev)
+        self.edges_per_graph = torch.from_numpy(npg * (npg - 1) // 2).to(dev)
+        self.batch = self._t['node_graph'].long()
+        self.node_attr = torch.zeros(self.num_nodes, dtype=torch.long, device=dev)
+        if degree is not None:
+            d = np.concatenate([np.asarray(x).reshape(-1) for x in degree]) if B else np.zeros(0)
+            assert d.shape[0] == self.num_nodes
+            self.degree_i32 = i32(np.rint(d))
+            # dtype as in the reference: fp32 from the empty-graph sampler (data_utils.py:104),
+            # int64 from preprocess (data_utils.py:62)
+            self.degree = torch.from_numpy(d.astype(np.float32 if degree_dtype is None else degree_dtype)).to(dev)
+        else:
+            self.degree_i32 = None
+            self.degree = None
+        # state
+        self.adj = torch.zeros(max(self.adj_words, 1), dtype=torch.int32, device=dev)
+        self.x0_edges = edges
+        if edges is not None:
+            ge = [np.asarray(e, dtype=np.int64).reshape(-1, 2) + node_ptr[b] for b, e in enumerate(edges)]
+            ge = np.concatenate(ge) if ge else np.zeros((0, 2), np.int64)
+            self.set_edges(self.adj, ge)
+            if degree is None:
+                deg = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
+                capi.check(capi.lib.edgehip_degree_from_adj(C_byref(L), self.adj.data_ptr(), deg.data_ptr(),
+                                                            capi.stream_ptr()), 'degree_from_adj')
+                self.degree_i32 = deg
+                self.degree = deg.long()
+        self._slice_dict, self._inc_dict = {}, {}
+
+    # ---- helpers -------------------------------------------------------------------------
+    def set_edges(self, adj, global_edges):
+        ge = torch.from_numpy(np.ascontiguousarray(global_edges, dtype=np.int32)).to(self.device)
+        capi.check(capi.lib.edgehip_adj_from_edges(C_byref(self.layout), capi.ptr(ge) if ge.numel() else None,
+                                                   ge.shape[0], adj.data_ptr(), capi.stream_ptr()), 'adj_from_edges')
+
+    def new_adj(self):
+        return torch.zeros_like(self.adj)
+
+    def to(self, device):
+        assert torch.device(device).type == self.device.type, 'GraphBatch is built on its device'
+        return self
+
+    def extract_edges(self, adj=None):
+        """edge_index [2,E] int64 (i<j, ascending pair order) and edge_slice [B+1] of a state."""
+        adj = self.adj if adj is None else adj
+        row_upper = torch.empty(max(self.num_nodes, 1), dtype=torch.int32, device=self.device)
+        edge_slice = torch.zeros(self.num_graphs + 1, dtype=torch.int64, device=self.device)
+        s = capi.stream_ptr()
+        capi.check(capi.lib.edgehip_count_edges(C_byref(self.layout), adj.data_ptr(), row_upper.data_ptr(),
+                                                edge_slice.data_ptr(), s), 'count_edges')
+        E = int(edge_slice[-1].item())
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=self.device)
+        capi.check(capi.lib.edgehip_extract_edges(C_byref(self.layout), adj.data_ptr(), row_upper.data_ptr(),
+                                                  edge_slice.data_ptr(), capi.ptr(edge_index) if E else None, E, s),
+                   'extract_edges')
+        return edge_index, edge_slice
+
+    # ---- reference-layout views (small batches only) --------------------------------------
+    @property
+    def full_edge_index(self):
+        rows, cols = [], []
+        for b, n in enumerate(self.host.nodes_per_graph.tolist()):
+            r, c = torch.triu_indices(n, n, 1)
+            rows.append(r + int(self.host.node_ptr[b]))
+            cols.append(c + int(self.host.node_ptr[b]))
+        return torch.stack([torch.cat(rows), torch.cat(cols)]).to(self.device)
+
+    def pair_bits(self, adj=None):
+        """Dense int64 [P] bit vector of a state in the reference's pair order (tests)."""
+        ei, _ = self.extract_edges(adj)
+        out = torch.zeros(self.num_pairs, dtype=torch.long, device=self.device)
+        if ei.shape[1]:
+            g = self.batch[ei[0]]
+            node0 = self._t['node_ptr'].long()[g]
+            n = self.nodes_per_graph[g]
+            i, j = ei[0] - node0, ei[1] - node0
+            k = self._t['pair_ptr'][g] + i * (2 * n - i - 1) // 2 + (j - i - 1)
+            out[k] = 1
+        return out
+
+    @property
+    def full_edge_attr(self):
+        return self.pair_bits()
+
+    def to_data_list(self):
+        """Per-graph results with local node ids, like PyG's Batch.to_data_list()."""
+        ei = self.edge_index.cpu()
+        sl = self._slice_dict['edge_index'].cpu().tolist()
+        out = []
+        for b in range(self.num_graphs):
+            e = ei[:, sl[b]:sl[b + 1]] - int(self.host.node_ptr[b])
+            out.append(SimpleNamespace(edge_index=e, num_nodes=int(self.host.nodes_per_graph[b]),
+                                       edge_attr=torch.ones(e.shape[1], dtype=torch.long),
+                                       node_attr=torch.zeros(int(self.host.nodes_per_graph[b]), dtype=torch.long)))
+        return out
+
+
+def C_byref(x):
+    import ctypes
+    return ctypes.byref(x)

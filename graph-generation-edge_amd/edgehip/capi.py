@@ -1,0 +1,126 @@
+"""ctypes binding of libedgehip.so (include/edgehip.h).
+
+The library is the product: if it is missing this module raises at import - there is no
+CPU or eager fallback.  Tensors are passed as raw device pointers (`tensor.data_ptr()`), the
+stream as `torch.cuda.current_stream().cuda_stream`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libedgehip.so')
+
+MAX_LAYERS = 8
+TILE_ROWS = 32
+PAIR_TILE = 32
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = 0, -1, -2, -3, -4
+_ERR = {ERR_ARG: 'bad argument', ERR_UNSUPPORTED: 'unsupported configuration', ERR_WORKSPACE: 'workspace too small',
+        ERR_LAUNCH: 'kernel launch failed'}
+STATUS_CAPACITY = 1
+
+vp = C.c_void_p
+
+
+class Layout(C.Structure):
+    _fields_ = [('num_graphs', C.c_int32), ('num_nodes', C.c_int32), ('num_tiles', C.c_int32),
+                ('max_nodes', C.c_int32), ('gid_base', C.c_int32), ('reserved', C.c_int32),
+                ('node_ptr', vp), ('node_graph', vp), ('adj_ptr', vp), ('adj_stride', vp), ('pair_ptr', vp),
+                ('tile_ptr', vp), ('tile_graph', vp), ('tile_row0', vp), ('tile_rows', vp)]
+
+
+class Counts(C.Structure):
+    _fields_ = [('k_total', C.c_int32), ('pair_tiles', C.c_int32), ('a_total', C.c_int64),
+                ('status', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Rng(C.Structure):
+    _fields_ = [('seed', C.c_uint64)]
+
+
+_PL = vp * MAX_LAYERS
+
+
+class GnnParams(C.Structure):
+    _fields_ = [('dim', C.c_int32), ('num_layers', C.c_int32), ('heads', C.c_int32 * MAX_LAYERS),
+                ('max_degree', C.c_int32), ('num_steps', C.c_int32)] + \
+        [(n, vp) for n in ('embedding_t_w', 'embedding_t_b', 'embedding_0_w', 'embedding_0_b', 'embedding_sel_w',
+                           'node_in_w', 'node_in_b', 'mlp_w0', 'mlp_b0', 'mlp_w2', 'mlp_b2',
+                           'global_w0', 'global_b0', 'global_w2', 'global_b2',
+                           'context_w0', 'context_b0', 'context_w2', 'context_b2',
+                           'gru_w_ih', 'gru_w_hh', 'gru_b_ih', 'gru_b_hh')] + \
+        [(n, _PL) for n in ('time_w', 'time_b', 'query_w', 'query_b', 'key_w', 'key_b', 'value_w', 'value_b',
+                            'skip_w', 'skip_b')] + \
+        [(n, vp) for n in ('node_out_w0', 'node_out_b0', 'node_out_w2', 'node_out_b2', 'node_out_w4', 'node_out_b4',
+                           'final_w0', 'final_b0', 'final_w2', 'final_b2', 'final_w4', 'final_b4', 'pos_emb')]
+
+
+EXPORTS = {
+    'edgehip_degree_from_adj': [C.POINTER(Layout), vp, vp, vp],
+    'edgehip_active_select_sample': [C.POINTER(Layout), vp, vp, vp, vp, C.c_int32, vp, C.POINTER(Rng), vp, vp, vp, vp, vp],
+    'edgehip_active_select_train': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp],
+    'edgehip_active_offsets': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp],
+    'edgehip_active_pairs_enumerate': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp],
+    'edgehip_q_sample_edges': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp, C.POINTER(Rng), vp, vp, vp, vp],
+    'edgehip_count_edges': [C.POINTER(Layout), vp, vp, vp, vp],
+    'edgehip_extract_edges': [C.POINTER(Layout), vp, vp, vp, vp, C.c_int64, vp],
+    'edgehip_adj_from_edges': [C.POINTER(Layout), vp, C.c_int64, vp, vp],
+    'edgehip_gnn_prepare': [C.POINTER(GnnParams), vp, vp],
+    'edgehip_gnn_forward': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp,
+                            vp, vp, vp, C.c_size_t, vp],
+    'edgehip_edge_resample': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp,
+                              C.POINTER(Rng), C.c_int32, vp, vp, vp, vp, C.c_int64, vp],
+    'edgehip_edge_ce_loss': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64,
+                             vp, vp, C.c_int64, vp],
+    'edgehip_sample_step': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp,
+                            C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
+    'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],
+}
+SIZE_EXPORTS = {
+    'edgehip_gnn_folded_floats': [C.POINTER(GnnParams)],
+    'edgehip_gnn_workspace_bytes': [C.POINTER(Layout), C.POINTER(GnnParams)],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: build it with `python __graft_entry__.py` '
+                          '(make -C graph-generation-edge_amd/csrc); there is no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    for name, args in EXPORTS.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    for name, args in SIZE_EXPORTS.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_size_t
+    lib.edgehip_version.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+class EdgeHipError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != OK:
+        raise EdgeHipError(f'{what}: {_ERR.get(rc, rc)} ({rc})')
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'edgehip needs contiguous tensors'
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    if torch.cuda.is_available():
+        return torch.cuda.current_stream().cuda_stream
+    return None

@@ -1,0 +1,247 @@
+/* edgehip.h - C ABI of libedgehip.so: EDGE's degree-guided binomial diffusion hot
+ * path as hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * Every entry point replaces a function of the reference (tufts-ml/graph-generation-EDGE);
+ * the citation after "replaces:" is file:line in the reference tree.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory; no entry point allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value: EDGEHIP_OK or a negative error code; nothing throws;
+ *   - data-dependent sizes (active nodes K, active pairs A, edges E) stay on the device:
+ *     kernels read them from `edgehip_counts` and launch over fixed upper bounds, so the
+ *     sampling loop needs no host synchronisation.
+ *
+ * State layout (replaces the reference's dense log-one-hot `[P,2]` state and its
+ * int64 `full_edge_index [2,P]`, datasets/data_utils.py:53-56): one symmetric BIT MATRIX
+ * per graph.  Graph b owns `n_b` rows of `adj_stride[b]` 32-bit words starting at word
+ * `adj_ptr[b]`; bit j of row i is 1 iff {i,j} is an edge.  Pair k of the reference's
+ * enumeration (`torch.triu_indices(n,n,1)`, row-major) is (i,j), k = i(2n-i-1)/2 + (j-i-1).
+ */
+#ifndef EDGEHIP_H
+#define EDGEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDGEHIP_OK 0
+#define EDGEHIP_ERR_ARG (-1)          /* null pointer, negative size, misaligned buffer */
+#define EDGEHIP_ERR_UNSUPPORTED (-2)  /* configuration outside what the kernels implement */
+#define EDGEHIP_ERR_WORKSPACE (-3)    /* workspace too small */
+#define EDGEHIP_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch */
+
+#define EDGEHIP_MAX_LAYERS 8
+#define EDGEHIP_TILE_ROWS 32          /* node tile: 32 consecutive nodes of ONE graph */
+#define EDGEHIP_PAIR_TILE 32          /* active-pair tile: 32 consecutive active pairs of ONE graph */
+
+/* Batch layout: the native form of the fields the path reads from a PyG Batch
+ * (datasets/data_utils.py:69-75).  Built once per batch. */
+typedef struct edgehip_layout {
+    int32_t num_graphs;          /* B */
+    int32_t num_nodes;           /* Nn = sum n_b */
+    int32_t num_tiles;           /* NT = sum ceil(n_b / 32) */
+    int32_t max_nodes;           /* max n_b */
+    int32_t gid_base;            /* global id of graph 0 (keys the counter-based RNG; rank offset) */
+    int32_t reserved;
+    const int32_t* node_ptr;     /* [B+1] first node of each graph */
+    const int32_t* node_graph;   /* [Nn]  graph of each node ('batch') */
+    const int64_t* adj_ptr;      /* [B+1] first word of each graph's bit matrix */
+    const int32_t* adj_stride;   /* [B]   words per row (>= ceil(n_b/32)) */
+    const int64_t* pair_ptr;     /* [B+1] prefix of n_b(n_b-1)/2 ('edges_per_graph' cumsum) */
+    const int32_t* tile_ptr;     /* [B+1] first tile of each graph */
+    const int32_t* tile_graph;   /* [NT] */
+    const int32_t* tile_row0;    /* [NT] first (global) node of the tile */
+    const int32_t* tile_rows;    /* [NT] rows in the tile, 1..32 */
+} edgehip_layout;
+
+/* Device-side counters written by edgehip_active_offsets and read by later kernels. */
+typedef struct edgehip_counts {
+    int32_t k_total;      /* active nodes in the batch */
+    int32_t pair_tiles;   /* total active-pair tiles */
+    int64_t a_total;      /* active pairs in the batch */
+    int32_t status;       /* 0, or a bit mask of EDGEHIP_STATUS_* raised by kernels */
+    int32_t reserved;
+} edgehip_counts;
+#define EDGEHIP_STATUS_CAPACITY 1   /* an optional output buffer was too small (output truncated) */
+
+/* Counter-based uniforms (Philox4x32-10) for throughput runs.  u = (x >> 8) * 2^-24, the
+ * grid torch.rand emits on CPU.  Keyed (seed; graph global id, step, stream, element), so
+ * results do not depend on how graphs are sharded over GPUs. */
+typedef struct edgehip_rng {
+    uint64_t seed;
+} edgehip_rng;
+
+/* ---- a8: degrees ---------------------------------------------------------------------
+ * replaces: BinomialDiffusionActive._compute_degree, diffusion/diffusion_binomial_active.py:92-95
+ * deg[i] = popcount(row i).  int32, exact. */
+int edgehip_degree_from_adj(const edgehip_layout* L, const uint32_t* adj, int32_t* deg, void* stream);
+
+/* ---- a9+a10: degree-guided active-node selection (sampling) ---------------------------
+ * replaces: _q_posterior_actives + log_sample_categorical + nonzero,
+ *           diffusion/diffusion_binomial_active.py:97-126, diffusion/diffusion_base.py:175-180
+ * n = max(d0 - deg, 0); log-probs = post_table[t_graph[b]][n] (host-built with the reference's
+ * exact torch op sequence, [T][nmax+1][2] fp32); node i is active iff
+ * g(u[i][1]) + lp1 > g(u[i][0]) + lp0, g(u) = -log(-log(u+1e-30)+1e-30).
+ * uniforms: [Nn,2] fp32, or NULL to use `rng` (stream 0).  gumbel_lut: NULL, or the 2^24-entry
+ * table of g(k*2^-24) built by the host libm (bit-exact decisions against a CPU reference).
+ * Outputs: flags[Nn] (0/1); act_nodes[Nn]: graph b's active nodes, ascending, as global ids in
+ * act_nodes[node_ptr[b] ...]; act_count[B]. */
+int edgehip_active_select_sample(const edgehip_layout* L, const int32_t* d0, const int32_t* deg,
+                                 const int32_t* t_graph, const float* post_table, int32_t nmax,
+                                 const float* uniforms, const edgehip_rng* rng, const float* gumbel_lut,
+                                 uint8_t* flags, int32_t* act_nodes, int32_t* act_count, void* stream);
+
+/* ---- a11: active nodes in training ----------------------------------------------------
+ * replaces: _q_set_actives, diffusion/diffusion_binomial_active.py:134-140
+ * active iff deg_tm1[i] > deg_t[i]. Outputs as above. */
+int edgehip_active_select_train(const edgehip_layout* L, const int32_t* deg_tm1, const int32_t* deg_t,
+                                uint8_t* flags, int32_t* act_nodes, int32_t* act_count, void* stream);
+
+/* ---- offsets of the compacted sets -----------------------------------------------------
+ * replaces: the implicit sizes of `.nonzero()` results, diffusion_binomial_active.py:126-128
+ * kptr[B+1] prefix of K_b; aptr[B+1] prefix of A_b = K_b(K_b-1)/2; tptr[B+1] prefix of
+ * ceil(A_b/32) pair tiles; totals into *counts (status is cleared). */
+int edgehip_active_offsets(const edgehip_layout* L, const int32_t* act_count, int32_t* kptr, int64_t* aptr,
+                           int32_t* tptr, edgehip_counts* counts, void* stream);
+
+/* ---- a10: materialise the reference's index lists ---------------------------------------
+ * replaces: active_node_indices / active_edge_indices, diffusion_binomial_active.py:126-128,140-143
+ * active_node_indices[K] int64 ascending; active_edge_indices[A] int64 ascending (indices into
+ * the reference's P enumeration), with global row/col ids.  Any output may be NULL.
+ * Capacities in elements; truncation raises EDGEHIP_STATUS_CAPACITY in counts->status. */
+int edgehip_active_pairs_enumerate(const edgehip_layout* L, const int32_t* act_nodes, const int32_t* kptr,
+                                   const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
+                                   int64_t* active_node_indices, int64_t node_cap,
+                                   int64_t* active_edge_indices, int64_t* row, int64_t* col, int64_t pair_cap,
+                                   void* stream);
+
+/* ---- a4-a7: forward noising --------------------------------------------------------------
+ * replaces: _q_sample_and_set_xtmin1_xt_given_x0, diffusion/diffusion_binomial_vanilla.py:192-212
+ *           (q_sample diffusion_base.py:154-163, _q_pred :272-288, _q_pred_one_timestep :226-243)
+ * For every edge of x0 (only those can survive: SURVEY App. A5): kept in x_{t-1} iff t==0 or
+ * g(u1)+q_cum[t-1][1] > g(u0)+q_cum[t-1][0]; kept in x_t iff kept in x_{t-1} and
+ * g(v1)+q_one[t][1] > g(v0)+q_one[t][0].  q_cum/q_one: [T][2] host-built log-probs of a source
+ * bit 1.  u_tm1/u_t: dense [P,2] uniforms addressed by pair index, or NULL to use rng (streams 2,3).
+ * adj_tm1/adj_t must be zero-filled by the caller. */
+int edgehip_q_sample_edges(const edgehip_layout* L, const uint32_t* adj0, const int32_t* t_graph,
+                           const float* q_cum, const float* q_one, const float* u_tm1, const float* u_t,
+                           const edgehip_rng* rng, const float* gumbel_lut, uint32_t* adj_tm1,
+                           uint32_t* adj_t, void* stream);
+
+/* ---- a17 epilogue: edge list of the state ------------------------------------------------
+ * replaces: the epilogue of DiffusionBase.sample, diffusion/diffusion_base.py:209-228
+ * count: edges_per_graph[B] and edge_slice[B+1] (prefix) from the upper triangle.
+ * extract: edge_index [2,E] int64 (row 0 = i, row 1 = j, global ids, i<j, ascending pair order),
+ * `edge_cap` = E the caller allocated (read edge_slice[B] after a sync). */
+int edgehip_count_edges(const edgehip_layout* L, const uint32_t* adj, int32_t* row_upper, int64_t* edge_slice,
+                        void* stream);
+int edgehip_extract_edges(const edgehip_layout* L, const uint32_t* adj, const int32_t* row_upper,
+                          const int64_t* edge_slice, int64_t* edge_index, int64_t edge_cap, void* stream);
+
+/* set bits of an edge list into a zero-filled bit matrix (host helper for x0; both directions).
+ * edges: [E,2] int32 global node ids. */
+int edgehip_adj_from_edges(const edgehip_layout* L, const int32_t* edges, int64_t num_edges, uint32_t* adj,
+                           void* stream);
+
+/* ---- a12-a15: the denoising network -------------------------------------------------------
+ * Parameters of TGNN_degree_guided (layers/layers.py:250-313), torch layouts ([out,in] row-major
+ * fp32), named after its state_dict. */
+typedef struct edgehip_gnn_params {
+    int32_t dim;                 /* must be 64 */
+    int32_t num_layers;          /* len(num_heads) <= 8 */
+    int32_t heads[EDGEHIP_MAX_LAYERS];   /* each in {1,2,4,8} */
+    int32_t max_degree;
+    int32_t num_steps;           /* T */
+    const float *embedding_t_w, *embedding_t_b, *embedding_0_w, *embedding_0_b, *embedding_sel_w;
+    const float *node_in_w, *node_in_b;
+    const float *mlp_w0, *mlp_b0, *mlp_w2, *mlp_b2;               /* time mlp */
+    const float *global_w0, *global_b0, *global_w2, *global_b2;   /* global_mlp */
+    const float *context_w0, *context_b0, *context_w2, *context_b2;
+    const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
+    const float *time_w[EDGEHIP_MAX_LAYERS], *time_b[EDGEHIP_MAX_LAYERS];
+    const float *query_w[EDGEHIP_MAX_LAYERS], *query_b[EDGEHIP_MAX_LAYERS];
+    const float *key_w[EDGEHIP_MAX_LAYERS], *key_b[EDGEHIP_MAX_LAYERS];
+    const float *value_w[EDGEHIP_MAX_LAYERS], *value_b[EDGEHIP_MAX_LAYERS];
+    const float *skip_w[EDGEHIP_MAX_LAYERS], *skip_b[EDGEHIP_MAX_LAYERS];
+    const float *node_out_w0, *node_out_b0, *node_out_w2, *node_out_b2, *node_out_w4, *node_out_b4;
+    const float *final_w0, *final_b0, *final_w2, *final_b2, *final_w4, *final_b4;
+    const float* pos_emb;        /* [T,64] sinusoidal table built on the host (layers.py:45-60) */
+} edgehip_gnn_params;
+
+/* Folded weights: products of the raw matrices that let the kernels skip work the reference
+ * does per node (DESIGN.md "Algebra").  `folded` is a device buffer of
+ * edgehip_gnn_folded_floats(P) floats; edgehip_gnn_prepare fills it and must be called again
+ * whenever the raw parameters change. */
+size_t edgehip_gnn_folded_floats(const edgehip_gnn_params* P);
+int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, void* stream);
+
+/* Workspace (bytes) for edgehip_gnn_forward / edgehip_sample_step / edgehip_loss_forward. */
+size_t edgehip_gnn_workspace_bytes(const edgehip_layout* L, const edgehip_gnn_params* P);
+
+/* replaces: TGNN_degree_guided.forward, layers/layers.py:315-383 (+ TransformerConv :354,
+ *           GRU :360, scatter-mean :342,367)
+ * Inputs: state bit matrix, its degrees, d0, per-graph t, the active set (flags, act_nodes, kptr,
+ * aptr, tptr, counts).  Output: `node_repr` [K_total,128] (compact, active-node order): the
+ * per-active-node vector v with  edge_logits(a,b) = final_tail(silu(v_a + v_b + final_b0)).
+ * Optional debug output h_out [Nn,64]: node state after the last layer (reference `nodes` at
+ * layers.py:371). */
+int edgehip_gnn_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                        const uint32_t* adj, const int32_t* deg, const int32_t* d0, const int32_t* t_graph,
+                        int32_t t_shared, const uint8_t* flags, const int32_t* act_nodes, const int32_t* kptr,
+                        const edgehip_counts* counts, float* node_repr, float* h_out, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* ---- a16: Bernoulli re-sampling of the active pairs ---------------------------------------
+ * replaces: final_out on active pairs layers.py:380-381, F.log_softmax active:153-154,
+ *           log_sample_categorical + in-place overwrite active:83-88
+ * For active pair k of graph b (a_p < a_q the p-th/q-th active node): logits -> log_softmax ->
+ * bit = g(u1)+lp1 > g(u0)+lp0; the state bit of {a_p,a_q} is OVERWRITTEN (both directions).
+ * uniforms: [A,2] in active-pair order, or NULL for rng (stream 1, keyed by the pair's index in
+ * the P enumeration).  Optional outputs (NULL to skip): logits_out [A,2], bits_out [A] (cap pair_cap).
+ * logits_in: NULL, or [A,2] externally supplied logits that replace the network's (parity tests:
+ * "sampled edges bit-exact given logits + uniforms"). `logits_are_logprobs` != 0 skips log_softmax. */
+int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                          const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
+                          const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
+                          const float* logits_in, int32_t logits_are_logprobs, const float* uniforms,
+                          const edgehip_rng* rng, int32_t step, const float* gumbel_lut, uint32_t* adj,
+                          float* logits_out, uint8_t* bits_out, int64_t pair_cap, void* stream);
+
+/* ---- a18: cross-entropy of the active pairs against x_{t-1} --------------------------------
+ * replaces: _compute_MC_KL_joint, diffusion/diffusion_binomial_active.py:157-181
+ * kl[b] = sum_k CE_k + 6.9078e-29*(n(n-1)/2 - A_b) + 6.9078e-29*n(n-1)/2.  tile_partial: scratch of
+ * counts->pair_tiles floats (capacity tile_cap).  Optional logits_out as above. */
+int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                         const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
+                         const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
+                         const uint32_t* adj_tm1, float* tile_partial, int64_t tile_cap, float* kl,
+                         float* logits_out, int64_t pair_cap, void* stream);
+
+/* ---- a16+a10+a12 fused: one reverse step for the whole batch --------------------------------
+ * replaces: BinomialDiffusionActive.p_sample, diffusion/diffusion_binomial_active.py:72-90
+ * Sequence: degree -> select -> offsets -> gnn_forward -> edge_resample, all on `stream`, no host
+ * sync.  `t` is the shared step; post_table as in edgehip_active_select_sample.  u_node [Nn,2] and
+ * u_pair [A,2] may be NULL (rng).  The scratch arrays live in `ws`. */
+int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                        uint32_t* adj, const int32_t* d0, int32_t t, const float* post_table, int32_t nmax,
+                        const float* u_node, const float* u_pair, const edgehip_rng* rng,
+                        const float* gumbel_lut, edgehip_counts* counts, void* ws, size_t ws_bytes,
+                        void* stream);
+
+/* ---- generic fp32 MFMA linear layer (exposed for tests / composition) -----------------------
+ * replaces: torch.nn.Linear calls of layers/layers.py:257-313
+ * Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]); K % 64 == 0, N % 32 == 0; act 0 none, 1 SiLU. */
+int edgehip_linear_fwd(const float* X, int64_t M, int32_t K, const float* W, const float* bias, int32_t N,
+                       int32_t act, float* Y, void* stream);
+
+const char* edgehip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGEHIP_H */

@@ -373,7 +373,7 @@ if __name__ == '__main__':
         gen_step('ragged', 9)
         gen_step('polblogs1', 100)
         gen_loss('toy', [3, 0])
-        gen_loss('toy', [22, 13], tag='_mid')
+        gen_loss('toy', [6, 4], tag='_mid')
         gen_loss('ragged', [0, 7, 47, 12, 1, 20])
         gen_loss('polblogs1', [100])
         gen_traj('toy')
