@@ -54,6 +54,7 @@ struct eh_gemm_desc {
     int num_tiles;
     int64_t M;                          // rows when tile_row0 == null
     const int32_t* m_dev;               // optional device-side row count overriding M
+    int prof_id;                        // kernel class for the optional event timer (prof.h)
 };
 
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream);

@@ -2,6 +2,7 @@
 // Skinny-K (64..576), tall-M (one row per node) shapes: each wave keeps a 32-row A fragment in
 // registers and streams W rows from L2; see gemm.h for the operand scheme.
 #include "gemm.h"
+#include "prof.h"
 
 template <int NACC>
 __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int nt_per_block) {
@@ -80,9 +81,9 @@ int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
     per = ((per + nacc - 1) / nacc) * nacc;
     split = (nt_total + per - 1) / per;
     if (nacc == 2)
-        hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per);
+        EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per));
     else
-        hipLaunchKernelGGL(k_gemm<1>, dim3(gx, split), dim3(256), 0, stream, d, per);
+        EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<1>, dim3(gx, split), dim3(256), 0, stream, d, per));
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }
@@ -92,6 +93,6 @@ extern "C" int edgehip_linear_fwd(const float* X, int64_t M, int32_t K, const fl
     EH_CHECK_ARG(X && W && Y && M >= 0);
     if (M == 0) return EDGEHIP_OK;
     eh_gemm_desc d = {};
-    d.A = X; d.lda = K; d.K1 = K; d.W = W; d.K = K; d.N = N; d.bias = bias; d.Y = Y; d.ldy = N; d.act = act; d.M = M;
+    d.A = X; d.lda = K; d.K1 = K; d.W = W; d.K = K; d.N = N; d.bias = bias; d.Y = Y; d.ldy = N; d.act = act; d.M = M; d.prof_id = EH_K_MISC;
     return eh_launch_gemm(d, eh_stream(stream));
 }

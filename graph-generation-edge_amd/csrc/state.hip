@@ -2,6 +2,7 @@
 // compaction, forward noising, edge extraction.  Integer / bit work, HBM- or latency-bound.
 // Compiled with -ffp-contract=off: every Gumbel decision is a plain fp32 add + compare.
 #include "common.h"
+#include "prof.h"
 
 // ---------------------------------------------------------------------------------------------
 // a8  degrees: deg[i] = popcount(row i).  8 lanes per row, strided words, shuffle reduce.
@@ -37,7 +38,7 @@ extern "C" int edgehip_degree_from_adj(const edgehip_layout* L, const uint32_t* 
     EH_CHECK_ARG(L && adj && deg);
     if (L->num_nodes == 0) return EDGEHIP_OK;
     int blocks = eh_cdiv((int64_t)L->num_nodes * 8, 256);
-    hipLaunchKernelGGL(k_row_popcount<false>, dim3(blocks), dim3(256), 0, eh_stream(stream), *L, adj, deg);
+    EH_PROF(EH_K_DEGREE, eh_stream(stream), hipLaunchKernelGGL(k_row_popcount<false>, dim3(blocks), dim3(256), 0, eh_stream(stream), *L, adj, deg));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -105,8 +106,8 @@ extern "C" int edgehip_active_select_sample(const edgehip_layout* L, const int32
     EH_CHECK_ARG(uniforms || rng);
     if (L->num_graphs == 0) return EDGEHIP_OK;
     edgehip_rng r = rng ? *rng : edgehip_rng{0};
-    hipLaunchKernelGGL(k_select<0>, dim3(L->num_graphs), dim3(256), 0, eh_stream(stream), *L, d0, deg, t_graph,
-                       post_table, nmax, uniforms, r, uniforms ? 0 : 1, gumbel_lut, flags, act_nodes, act_count);
+    EH_PROF(EH_K_SELECT, eh_stream(stream), hipLaunchKernelGGL(k_select<0>, dim3(L->num_graphs), dim3(256), 0, eh_stream(stream), *L, d0, deg, t_graph,
+                       post_table, nmax, uniforms, r, uniforms ? 0 : 1, gumbel_lut, flags, act_nodes, act_count));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(256) void k_offsets(int B, const int32_t* __restric
 extern "C" int edgehip_active_offsets(const edgehip_layout* L, const int32_t* act_count, int32_t* kptr, int64_t* aptr,
                                       int32_t* tptr, edgehip_counts* counts, void* stream) {
     EH_CHECK_ARG(L && act_count && kptr && aptr && tptr && counts);
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(256), 0, eh_stream(stream), L->num_graphs, act_count, kptr, aptr, tptr,
-                       counts);
+    EH_PROF(EH_K_OFFSETS, eh_stream(stream), hipLaunchKernelGGL(k_offsets, dim3(1), dim3(256), 0, eh_stream(stream), L->num_graphs, act_count, kptr, aptr, tptr,
+                       counts));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -309,8 +310,8 @@ extern "C" int edgehip_q_sample_edges(const edgehip_layout* L, const uint32_t* a
     if (L->num_nodes == 0) return EDGEHIP_OK;
     edgehip_rng r = rng ? *rng : edgehip_rng{0};
     int blocks = eh_cdiv((int64_t)L->num_nodes * 8, 256);
-    hipLaunchKernelGGL(k_q_sample, dim3(blocks), dim3(256), 0, eh_stream(stream), *L, adj0, t_graph, q_cum, q_one,
-                       u_tm1, u_t, r, (u_tm1 && u_t) ? 0 : 1, gumbel_lut, adj_tm1, adj_t);
+    EH_PROF(EH_K_QSAMPLE, eh_stream(stream), hipLaunchKernelGGL(k_q_sample, dim3(blocks), dim3(256), 0, eh_stream(stream), *L, adj0, t_graph, q_cum, q_one,
+                       u_tm1, u_t, r, (u_tm1 && u_t) ? 0 : 1, gumbel_lut, adj_tm1, adj_t));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }

@@ -96,6 +96,13 @@ def _load():
         f.argtypes = args
         f.restype = C.c_size_t
     lib.edgehip_version.restype = C.c_char_p
+    lib.edgehip_prof_enable.argtypes = [C.c_int]
+    lib.edgehip_prof_enable.restype = C.c_int
+    lib.edgehip_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    lib.edgehip_prof_collect.restype = C.c_int
+    lib.edgehip_prof_kernel_name.argtypes = [C.c_int32]
+    lib.edgehip_prof_kernel_name.restype = C.c_char_p
+    lib.edgehip_prof_num_kernels.restype = C.c_int32
     return lib
 
 
@@ -109,6 +116,17 @@ class EdgeHipError(RuntimeError):
 def check(rc, what=''):
     if rc != OK:
         raise EdgeHipError(f'{what}: {_ERR.get(rc, rc)} ({rc})')
+
+
+PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels')
+
+
+def prof_collect():
+    """{kernel class: (total ms, launches)} since the last collect (needs edgehip_prof_enable(1))."""
+    n = lib.edgehip_prof_num_kernels()
+    ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+    check(lib.edgehip_prof_collect(ms, cnt, n), 'prof_collect')
+    return {lib.edgehip_prof_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
 
 def ptr(t):

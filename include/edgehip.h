@@ -239,6 +239,16 @@ int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_params* P, co
 int edgehip_linear_fwd(const float* X, int64_t M, int32_t K, const float* W, const float* bias, int32_t N,
                        int32_t act, float* Y, void* stream);
 
+/* ---- measurement hooks (no counterpart in the reference; used by bench.py's roofline leg) -------
+ * When enabled, every kernel launch of the path is bracketed by HIP events on its launch stream.
+ * collect() synchronises on those events and returns, per kernel class, the summed device time (ms)
+ * and the number of launches since the last collect; arrays are HOST memory of
+ * edgehip_prof_num_kernels() entries.  Off by default (one branch per launch). */
+int edgehip_prof_enable(int on);
+int edgehip_prof_collect(double* ms_host, int64_t* launches_host, int32_t n);
+const char* edgehip_prof_kernel_name(int32_t id);
+int32_t edgehip_prof_num_kernels(void);
+
 const char* edgehip_version(void);
 
 #ifdef __cplusplus

@@ -110,9 +110,10 @@ def test_forward_noising_and_train_actives(case, tl):
     tabs = model._tables(b.device, 0)
     a1, a2 = b.new_adj(), b.new_adj()
     tg = t.to(torch.int32).cuda()
+    u1d, u3d = us[1].cuda(), us[3].cuda()      # keep the device copies alive across the call
     capi.check(capi.lib.edgehip_q_sample_edges(byref(b.layout), b.adj.data_ptr(), tg.data_ptr(),
                                                tabs['q_cum'].data_ptr(), tabs['q_one'].data_ptr(),
-                                               us[1].cuda().data_ptr(), us[3].cuda().data_ptr(), None,
+                                               u1d.data_ptr(), u3d.data_ptr(), None,
                                                tabs['lut'].data_ptr(), a1.data_ptr(), a2.data_ptr(), capi.stream_ptr()))
     assert torch.equal(b.pair_bits(a1).cpu(), ob.log_full_edge_attr_tmin1.argmax(1))
     assert torch.equal(b.pair_bits(a2).cpu(), ob.log_full_edge_attr_t.argmax(1))
