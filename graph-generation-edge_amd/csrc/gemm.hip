@@ -5,59 +5,69 @@
 #include "prof.h"
 
 template <int NACC>
-__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int nt_per_block) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
+__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) {
+    __shared__ __attribute__((aligned(16))) float wt[NACC * 32 * EH_WPITCH];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int tile = blockIdx.x * 4 + wave;
+    int ntiles;
+    int64_t M = 0;
+    if (d.tile_row0) {
+        ntiles = d.num_tiles;
+    } else {
+        M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
+        ntiles = (int)((M + 31) / 32);
+    }
+    if (blockIdx.x * 4 >= ntiles) return;          // block-uniform: nothing to do
+    const bool live = tile < ntiles;               // idle waves still stage weights and hit barriers
+    if (!live) tile = ntiles - 1;
     int row0, rows, g = 0;
     if (d.tile_row0) {
-        if (tile >= d.num_tiles) return;
         row0 = d.tile_row0[tile]; rows = d.tile_rows[tile]; g = d.tile_graph[tile];
     } else {
-        int64_t M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
-        int64_t r0 = (int64_t)tile * 32;
-        if (r0 >= M) return;
-        row0 = (int)r0; rows = (int)((M - r0) < 32 ? (M - r0) : 32);
+        row0 = tile * 32; rows = (int)((M - row0) < 32 ? (M - row0) : 32);
     }
     const int r = lane & 31, hh = lane >> 5;
     const int64_t arow = row0 + (r < rows ? r : rows - 1);
     const float* ap = d.A + arow * d.lda + hh * 32;
     const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
-    const int nt_total = d.N >> 5;
-    const int nt0 = blockIdx.y * nt_per_block;
-    const int nt1 = (nt0 + nt_per_block < nt_total) ? nt0 + nt_per_block : nt_total;
-    for (int nt = nt0; nt < nt1; nt += NACC) {
+    const int ng_total = d.N / (32 * NACC);
+    const int ng0 = blockIdx.y * ng_per_block;
+    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
+    const bool single = d.K == 64;
+    eh_frag a;
+    if (single) eh_load_frag(a, ap);
+    for (int ng = ng0; ng < ng1; ++ng) {
         f32x16 acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
         for (int kc = 0; kc < d.K; kc += 64) {
-            eh_frag a;
-            eh_load_frag(a, (kc < d.K1) ? ap + kc : ap2 + (kc - d.K1));
+            __syncthreads();
+            eh_stage_w<NACC * 32>(wt, d.W, d.K, ng * NACC * 32, kc);
+            if (!single) eh_load_frag(a, (kc < d.K1) ? ap + kc : ap2 + (kc - d.K1));
+            __syncthreads();
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
-                if (nt + j < nt1) {
-                    eh_frag b;
-                    eh_load_frag(b, d.W + (int64_t)((nt + j) * 32 + r) * d.K + kc + hh * 32);
-                    eh_mma64(acc[j], a, b);
-                }
+                eh_frag b;
+                eh_load_frag_lds(b, wt, j * 32 + r, hh);
+                eh_mma64(acc[j], a, b);
             }
         }
+        if (!live) continue;
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
-            if (nt + j < nt1) {
-                const int col = (nt + j) * 32 + r;
-                float add0 = d.bias ? d.bias[col] : 0.0f;
-                if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
-                const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
+            const int col = (ng * NACC + j) * 32 + r;
+            float add0 = d.bias ? d.bias[col] : 0.0f;
+            if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
+            const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int rr = eh_crow(i, lane);
-                    if (rr < rows) {
-                        int64_t grow = row0 + rr;
-                        float v = acc[j][i] + add0;
-                        if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
-                        if (d.act == 1) v = eh_silu(v);
-                        d.Y[grow * d.ldy + col] = v;
-                    }
+            for (int i = 0; i < 16; ++i) {
+                int rr = eh_crow(i, lane);
+                if (rr < rows) {
+                    int64_t grow = row0 + rr;
+                    float v = acc[j][i] + add0;
+                    if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
+                    if (d.act == 1) v = eh_silu(v);
+                    d.Y[grow * d.ldy + col] = v;
                 }
             }
         }
@@ -72,14 +82,12 @@ int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
     int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
     if (tiles <= 0) return EDGEHIP_OK;
     int gx = (int)((tiles + 3) / 4);
-    int nt_total = d.N >> 5;
-    const int nacc = nt_total >= 2 ? 2 : 1;
-    int max_split = nt_total / nacc;
+    const int nacc = (d.N % 64 == 0) ? 2 : 1;
+    const int ng_total = d.N / (32 * nacc);
     int want = (2048 + gx - 1) / gx;
-    int split = want < 1 ? 1 : (want > max_split ? max_split : want);
-    int per = (nt_total + split - 1) / split;
-    per = ((per + nacc - 1) / nacc) * nacc;
-    split = (nt_total + per - 1) / per;
+    int split = want < 1 ? 1 : (want > ng_total ? ng_total : want);
+    int per = (ng_total + split - 1) / split;
+    split = (ng_total + per - 1) / per;
     if (nacc == 2)
         EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per));
     else

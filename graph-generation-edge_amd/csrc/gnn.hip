@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_node_in(edgehip_layout L, int max_degre
                                                  const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
                                                  const uint8_t* __restrict__ flags, float* __restrict__ h0,
                                                  float* __restrict__ part) {
-    int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (tile >= L.num_tiles) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
@@ -359,14 +359,32 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
 // their online-softmax states merged at the end.  Neighbour ids are popped from the row words with
 // scalar bit ops (ascending j, like the reference's edge order).
 // --------------------------------------------------------------------------------------------
+// 8-lane group reductions with DPP (no LDS crossbar): quad xor-1, quad xor-2, then half-row mirror.
+__device__ static inline float eh_dpp_f(float v, const int ctrl_sel) {
+    int t;
+    if (ctrl_sel == 0) t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
+    else if (ctrl_sel == 1) t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);
+    else t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, t);
+}
+__device__ static inline float eh_group8_sum(float v) {
+    v += eh_dpp_f(v, 0);
+    v += eh_dpp_f(v, 1);
+    v += eh_dpp_f(v, 2);
+    return v;
+}
+
 template <int HEADS>
 __global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint32_t* __restrict__ adj,
                                                    const float* __restrict__ hsrc, const float* __restrict__ Qt,
                                                    float* __restrict__ Z) {
     constexpr int NSLOT = 8 / HEADS;
     constexpr int H = HEADS * 64;
+    constexpr int U = 4;                 // neighbours in flight per slot: hubs are a latency chain otherwise
     const int lane = threadIdx.x & 63;
-    const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform by construction; readfirstlane tells the compiler, so the row walk below stays
+    // in SGPRs / scalar branches instead of exec-masked vector code
+    const int node = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (node >= L.num_nodes) return;
     const int b = L.node_graph[node];
     const int node0 = L.node_ptr[b];
@@ -382,50 +400,75 @@ __global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint3
         for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; acc[d] = 0.f; acc[4 + d] = 0.f; }
     }
     float m = -INFINITY, lsum = 0.f;
-    for (int w0 = 0; w0 < stride; w0 += 64) {
-        uint32_t word = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
-        unsigned long long nz = __ballot(word != 0u);
-        while (nz) {
+    // wave-uniform neighbour iterator over the set bits of the row (ascending j)
+    int w0 = -64;
+    uint32_t word = 0u, wv = 0u;
+    unsigned long long nz = 0ull;
+    int jbase = 0;
+    bool done = false;
+    auto next = [&]() -> int {
+        while (wv == 0u) {
+            if (nz == 0ull) {
+                if (done || w0 + 64 >= stride) { done = true; return -1; }
+                w0 += 64;
+                word = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+                nz = __ballot(word != 0u);
+                continue;
+            }
             int src = __ffsll((long long)nz) - 1;
             nz &= nz - 1;
-            uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
-            int jbase = node0 + (w0 + src) * 32;
-            while (wv) {
-                int myj = -1;
+            wv = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
+            jbase = node0 + (w0 + src) * 32;
+        }
+        int j = jbase + __ffs((int)wv) - 1;
+        wv &= wv - 1;
+        return j;
+    };
+    while (true) {
+        int myj[U];
+        int first = -1;
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    if (wv) {
-                        int j = jbase + __ffs((int)wv) - 1;
-                        wv &= wv - 1;
-                        if (slot == s) myj = j;
-                    }
-                }
-                float x[8];
-                float sc = 0.f;
-                if (myj >= 0) {
-                    const f32x4* xp = reinterpret_cast<const f32x4*>(hsrc + (size_t)myj * 64 + c * 8);
-                    f32x4 x0 = xp[0], x1 = xp[1];
+        for (int u = 0; u < U; ++u) {
+            myj[u] = -1;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) { x[d] = x0[d]; x[4 + d] = x1[d]; }
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) sc += q[d] * x[d];
-                } else {
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) x[d] = 0.f;
-                }
-                sc += __shfl_xor(sc, 1);
-                sc += __shfl_xor(sc, 2);
-                sc += __shfl_xor(sc, 4);
-                if (myj >= 0) {
-                    float mn = fmaxf(m, sc);
-                    float resc = expf(m - mn);      // m = -inf on the first neighbour: exp(-inf) = 0
-                    float p = expf(sc - mn);
-                    lsum = lsum * resc + p;
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) acc[d] = acc[d] * resc + p * x[d];
-                    m = mn;
-                }
+            for (int s = 0; s < NSLOT; ++s) {
+                int j = next();
+                if (u == 0 && s == 0) first = j;
+                if (slot == s) myj[u] = j;
             }
+        }
+        if (first < 0) break;
+        f32x4 xa[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4* xp = reinterpret_cast<const f32x4*>(hsrc + (size_t)(myj[u] >= 0 ? myj[u] : node) * 64 + c * 8);
+            xa[u] = xp[0]; xb[u] = xp[1];
+        }
+        float sc[U];
+        float mn = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t += q[d] * xa[u][d] + q[4 + d] * xb[u][d];
+            t = eh_group8_sum(t);
+            sc[u] = (myj[u] >= 0) ? t : -INFINITY;
+            mn = fmaxf(mn, sc[u]);
+        }
+        if (mn > -INFINITY) {           // this slot saw at least one neighbour so far
+            float resc = __expf(m - mn);      // m = -inf before the first neighbour: exp(-inf) = 0
+            float p[U], ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { p[u] = __expf(sc[u] - mn); ps += p[u]; }
+            lsum = lsum * resc + ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float a0 = acc[d] * resc, a1 = acc[4 + d] * resc;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a0 += p[u] * xa[u][d]; a1 += p[u] * xb[u][d]; }
+                acc[d] = a0; acc[4 + d] = a1;
+            }
+            m = mn;
         }
     }
     if (NSLOT > 1) {
@@ -433,8 +476,8 @@ __global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint3
         for (int off = 8 * HEADS; off < 64; off <<= 1) {
             float m2 = __shfl_xor(m, off), l2 = __shfl_xor(lsum, off);
             float mn = fmaxf(m, m2);
-            float s1 = (m == -INFINITY) ? 0.f : expf(m - mn);
-            float s2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+            float s1 = (m == -INFINITY) ? 0.f : __expf(m - mn);
+            float s2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
             lsum = lsum * s1 + l2 * s2;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -462,8 +505,10 @@ __global__ __launch_bounds__(256) void k_gru(edgehip_layout L, const float* __re
                                              const float* __restrict__ w_hh, const float* __restrict__ b_ih,
                                              const float* __restrict__ b_hh, const float* __restrict__ xin,
                                              const float* __restrict__ hprev, float* __restrict__ hnew) {
+    // weight fragments straight from L2 (each is used once per wave; staging them through LDS with two
+    // barriers per column tile measured 15 % slower here)
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile >= L.num_tiles) return;
     const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
     const int r = lane & 31, hh = lane >> 5;
@@ -490,8 +535,8 @@ __global__ __launch_bounds__(256) void k_gru(edgehip_layout L, const float* __re
             int rr = eh_crow(i, lane);
             if (rr < rows) {
                 size_t o = (size_t)(row0 + rr) * 64 + col;
-                float rg = 1.0f / (1.0f + expf(-(ar[i] + bir)));
-                float zg = 1.0f / (1.0f + expf(-(az[i] + biz)));
+                float rg = 1.0f / (1.0f + __expf(-(ar[i] + bir)));
+                float zg = 1.0f / (1.0f + __expf(-(az[i] + biz)));
                 float ng = tanhf((ain[i] + bin) + rg * (ahn[i] + bhn));
                 float hp = hprev[o];
                 hnew[o] = (1.0f - zg) * ng + zg * hp;
@@ -506,31 +551,39 @@ __global__ __launch_bounds__(256) void k_gru(edgehip_layout L, const float* __re
 __global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __restrict__ w0 /*[256,128]*/,
                                              const float* __restrict__ cbias, const float* __restrict__ h,
                                              float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float wt[64 * EH_WPITCH];
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= L.num_tiles) return;
+    int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool live = tile < L.num_tiles;
+    if (!live) tile = L.num_tiles - 1;
     const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
     const int r = lane & 31, hh = lane >> 5;
     const int64_t arow = row0 + (r < rows ? r : rows - 1);
     eh_frag a;
     eh_load_frag(a, h + arow * 64 + hh * 32);
 #pragma unroll 1
-    for (int nt = 0; nt < 8; ++nt) {
-        f32x16 acc = eh_zero16();
-        eh_frag bf;
-        eh_load_frag(bf, w0 + (size_t)(nt * 32 + r) * 128 + hh * 32);
-        eh_mma64(acc, a, bf);
-        const int col = nt * 32 + r;
-        const float cb = cbias[(size_t)g * 256 + col];
-        float s = 0.f;
+    for (int np = 0; np < 4; ++np) {
+        __syncthreads();
+        eh_stage_w<64>(wt, w0, 128, np * 64, 0);
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int rr = eh_crow(i, lane);
-            float v = eh_silu(acc[i] + cb);
-            s += (rr < rows) ? v : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            f32x16 acc = eh_zero16();
+            eh_frag bf;
+            eh_load_frag_lds(bf, wt, j * 32 + r, hh);
+            eh_mma64(acc, a, bf);
+            const int col = np * 64 + j * 32 + r;
+            const float cb = cbias[(size_t)g * 256 + col];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rr = eh_crow(i, lane);
+                float v = eh_silu(acc[i] + cb);
+                s += (rr < rows) ? v : 0.f;
+            }
+            s += __shfl_xor(s, 32);
+            if (live && lane < 32) part[(size_t)tile * 256 + col] = s;
         }
-        s += __shfl_xor(s, 32);
-        if (lane < 32) part[(size_t)tile * 256 + col] = s;
     }
 }
 
@@ -543,7 +596,7 @@ __global__ __launch_bounds__(256) void k_gather_active(edgehip_layout L, edgehip
                                                        const int32_t* __restrict__ kptr, const float* __restrict__ h,
                                                        const float* __restrict__ ctx, const int32_t* __restrict__ deg,
                                                        const int32_t* __restrict__ d0, float* __restrict__ X) {
-    int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (tile >= L.num_tiles) return;
     int g = L.tile_graph[tile];
     int node0 = L.node_ptr[g];
@@ -694,7 +747,7 @@ struct eh_pair_args {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) {
     __shared__ float hid[4][32][65];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int total = a.counts->pair_tiles;
     const int B = L.num_graphs;
     for (int tg = blockIdx.x; tg * 4 < total; tg += gridDim.x) {
