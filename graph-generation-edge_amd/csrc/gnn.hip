@@ -374,33 +374,20 @@ __device__ static inline float eh_group8_sum(float v) {
     return v;
 }
 
+// One target node: walk the set bits of its bit-matrix row (wave-uniform iterator, ascending j),
+// keep U neighbours per slot in flight, online softmax.  q: this lane's 8 channels of qt for its head.
+// out: this lane's 8 channels of z = sum_j alpha_j h_j (valid in every slot after the merge).
 template <int HEADS>
-__global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint32_t* __restrict__ adj,
-                                                   const float* __restrict__ hsrc, const float* __restrict__ Qt,
-                                                   float* __restrict__ Z) {
+__device__ static inline void eh_attend(const uint32_t* __restrict__ rowp, int stride, int node0, int self_node,
+                                        const float* __restrict__ hsrc, const float (&q)[8], int lane, float (&out)[8]) {
     constexpr int NSLOT = 8 / HEADS;
-    constexpr int H = HEADS * 64;
     constexpr int U = 4;                 // neighbours in flight per slot: hubs are a latency chain otherwise
-    const int lane = threadIdx.x & 63;
-    // wave-uniform by construction; readfirstlane tells the compiler, so the row walk below stays
-    // in SGPRs / scalar branches instead of exec-masked vector code
-    const int node = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (node >= L.num_nodes) return;
-    const int b = L.node_graph[node];
-    const int node0 = L.node_ptr[b];
-    const int stride = L.adj_stride[b];
-    const uint32_t* rowp = adj + L.adj_ptr[b] + (int64_t)(node - node0) * stride;
     const int grp = lane >> 3, c = lane & 7;
-    const int head = grp % HEADS, slot = grp / HEADS;
-    float q[8], acc[8];
-    {
-        const f32x4* qp = reinterpret_cast<const f32x4*>(Qt + (size_t)node * H + head * 64 + c * 8);
-        f32x4 q0 = qp[0], q1 = qp[1];
+    const int slot = grp / HEADS;
+    float acc[8];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; acc[d] = 0.f; acc[4 + d] = 0.f; }
-    }
+    for (int d = 0; d < 8; ++d) acc[d] = 0.f;
     float m = -INFINITY, lsum = 0.f;
-    // wave-uniform neighbour iterator over the set bits of the row (ascending j)
     int w0 = -64;
     uint32_t word = 0u, wv = 0u;
     unsigned long long nz = 0ull;
@@ -441,7 +428,7 @@ __global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint3
         f32x4 xa[U], xb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f32x4* xp = reinterpret_cast<const f32x4*>(hsrc + (size_t)(myj[u] >= 0 ? myj[u] : node) * 64 + c * 8);
+            const f32x4* xp = reinterpret_cast<const f32x4*>(hsrc + (size_t)(myj[u] >= 0 ? myj[u] : self_node) * 64 + c * 8);
             xa[u] = xp[0]; xb[u] = xp[1];
         }
         float sc[U];
@@ -487,11 +474,39 @@ __global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint3
             m = mn;
         }
     }
+    float inv = 1.0f / (lsum + 1e-16f);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) out[d] = acc[d] * inv;
+}
+
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint32_t* __restrict__ adj,
+                                                   const float* __restrict__ hsrc, const float* __restrict__ Qt,
+                                                   float* __restrict__ Z) {
+    constexpr int H = HEADS * 64;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane tells the compiler, so the row walk stays in SGPRs /
+    // scalar branches instead of exec-masked vector code
+    const int node = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (node >= L.num_nodes) return;
+    const int b = L.node_graph[node];
+    const int node0 = L.node_ptr[b];
+    const int stride = L.adj_stride[b];
+    const uint32_t* rowp = adj + L.adj_ptr[b] + (int64_t)(node - node0) * stride;
+    const int grp = lane >> 3, c = lane & 7;
+    const int head = grp % HEADS, slot = grp / HEADS;
+    float q[8], z[8];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(Qt + (size_t)node * H + head * 64 + c * 8);
+        f32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
+    }
+    eh_attend<HEADS>(rowp, stride, node0, node, hsrc, q, lane, z);
     if (slot == 0) {
-        float inv = 1.0f / (lsum + 1e-16f);
         f32x4 o0, o1;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { o0[d] = acc[d] * inv; o1[d] = acc[4 + d] * inv; }
+        for (int d = 0; d < 4; ++d) { o0[d] = z[d]; o1[d] = z[4 + d]; }
         f32x4* zp = reinterpret_cast<f32x4*>(Z + (size_t)node * H + head * 64 + c * 8);
         zp[0] = o0; zp[1] = o1;
     }
@@ -588,6 +603,218 @@ __global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __re
 }
 
 // --------------------------------------------------------------------------------------------
+// Fused layer: for one node tile (32 nodes of one graph, one 256-thread block)
+//   A  qt   = Mcat h + qbias_g                      -> LDS            (MFMA, 2h column tiles over 4 waves)
+//   B  z    = attention over the bit rows           -> LDS in place   (8 targets per wave)
+//   C  conv = silu(Ocat [z | h] + biases)           -> LDS            (MFMA, K split over the waves + reduce)
+//   D  h'   = GRU(conv, h)                          -> global + LDS   (MFMA, gates split over the waves)
+//   E  part = column sums of silu(Wc1 h' + cbias_g) -> global         (MFMA)
+// qt and z (2 x 2 KB per node and layer) never touch HBM; per layer the kernel reads h (256 B/node),
+// the bit row and the L2-resident neighbour rows, and writes h'.
+// --------------------------------------------------------------------------------------------
+struct eh_layer_args {
+    const uint32_t* adj; const float* hprev; const int32_t* deg;
+    const float* Mcat; const float* qbias; int ldq;
+    const float* Ocat; const float* obias0; const float* obias1;
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    const float* cw0; const float* cbias;
+    float* hnew; float* part;
+};
+
+#define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
+#define EH_TSZ (32 * EH_TP)
+
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a) {
+    constexpr int H = HEADS * 64, QP = H + 4;
+    constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ];
+    float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
+    float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
+    float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
+    float* mt = lds + 4 * EH_TSZ;       // [32][68]   conv
+    float* ht = lds + 5 * EH_TSZ;       // [32][68]   h'
+    float* hp = lds + R1;               // [32][68]   h (layer input / GRU hidden)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int tile = blockIdx.x;
+    const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
+    const int r = lane & 31, hh = lane >> 5;
+
+    // ---- phase 0: h tile -> LDS (full-line loads)
+#pragma unroll
+    for (int i = tid; i < 512; i += 256) {
+        int row = i >> 4, c4 = i & 15;
+        int src = row0 + (row < rows ? row : rows - 1);
+        *reinterpret_cast<f32x4*>(hp + row * EH_TP + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(a.hprev + (size_t)src * 64 + c4 * 4);
+    }
+    __syncthreads();
+
+    // ---- phase A: qt
+    {
+        eh_frag af;
+        eh_load_frag_lds(af, hp, r, hh);
+        for (int nt = wave; nt < 2 * HEADS; nt += 4) {
+            eh_frag bf;
+            eh_load_frag(bf, a.Mcat + (size_t)(nt * 32 + r) * 64 + hh * 32);
+            f32x16 acc = eh_zero16();
+            eh_mma64(acc, af, bf);
+            const int col = nt * 32 + r;
+            const float qb = a.qbias[(size_t)g * a.ldq + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) qz[eh_crow(i, lane) * QP + col] = acc[i] + qb;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: attention, 8 targets per wave, z overwrites qt
+    {
+        const int node0 = L.node_ptr[g];
+        const int stride = L.adj_stride[g];
+        const uint32_t* gadj = a.adj + L.adj_ptr[g];
+        const int grp = lane >> 3, c = lane & 7;
+        const int head = grp % HEADS, slot = grp / HEADS;
+        for (int k = 0; k < 8; ++k) {
+            const int rr = wave * 8 + k;
+            if (rr >= rows) break;
+            const int node = row0 + rr;
+            float* qp = qz + rr * QP + head * 64 + c * 8;
+            float q[8], z[8];
+            {
+                f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
+            }
+            eh_attend<HEADS>(gadj + (int64_t)(node - node0) * stride, stride, node0, node, a.hprev, q, lane, z);
+            if (slot == 0) {
+                f32x4 o0, o1;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { o0[d] = z[d]; o1[d] = z[4 + d]; }
+                *reinterpret_cast<f32x4*>(qp) = o0;
+                *reinterpret_cast<f32x4*>(qp + 4) = o1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1); K chunks split over the waves
+    {
+        f32x16 acc0 = eh_zero16(), acc1 = eh_zero16();
+        for (int ch = wave; ch < HEADS + 1; ch += 4) {
+            eh_frag af, bf;
+            if (ch < HEADS) {
+                const float* p = qz + r * QP + ch * 64 + hh * 32;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            } else {
+                eh_load_frag_lds(af, hp, r, hh);
+            }
+            eh_load_frag(bf, a.Ocat + (size_t)r * (H + 64) + ch * 64 + hh * 32);
+            eh_mma64(acc0, af, bf);
+            eh_load_frag(bf, a.Ocat + (size_t)(32 + r) * (H + 64) + ch * 64 + hh * 32);
+            eh_mma64(acc1, af, bf);
+        }
+        __syncthreads();                      // every wave is done reading qz
+        float* mine = pt + wave * EH_TSZ;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int rr = eh_crow(i, lane);
+            mine[rr * EH_TP + r] = acc0[i];
+            mine[rr * EH_TP + 32 + r] = acc1[i];
+        }
+        __syncthreads();
+        const int row = tid >> 3, c0 = (tid & 7) * 8;
+        const bool hasnbr = a.deg[row0 + (row < rows ? row : rows - 1)] > 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(pt + row * EH_TP + c0 + 4 * q4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(pt + w * EH_TSZ + row * EH_TP + c0 + 4 * q4);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int col = c0 + 4 * q4 + e;
+                float x = v[e] + a.obias0[(size_t)g * 64 + col];
+                if (hasnbr) x += a.obias1[(size_t)g * 64 + col];
+                v[e] = eh_silu(x);
+            }
+            *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0 + 4 * q4) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: GRU.  wave = (column tile ct, gate part): part 0 -> r and i_n, part 1 -> z and h_n
+    {
+        const int ct = wave & 1, part = wave >> 1;
+        const int wr = ct * 32 + r, col = ct * 32 + r;
+        eh_frag am, ah, bf;
+        eh_load_frag_lds(am, mt, r, hh);
+        eh_load_frag_lds(ah, hp, r, hh);
+        f32x16 g0 = eh_zero16(), g1 = eh_zero16();
+        float* xz = xg + (ct * 2 + 0) * 1024;
+        float* xh = xg + (ct * 2 + 1) * 1024;
+        if (part == 1) {
+            eh_load_frag(bf, a.w_ih + (size_t)(64 + wr) * 64 + hh * 32);  eh_mma64(g0, am, bf);
+            eh_load_frag(bf, a.w_hh + (size_t)(64 + wr) * 64 + hh * 32);  eh_mma64(g0, ah, bf);
+            eh_load_frag(bf, a.w_hh + (size_t)(128 + wr) * 64 + hh * 32); eh_mma64(g1, ah, bf);
+            const float biz = a.b_ih[64 + col] + a.b_hh[64 + col], bhn = a.b_hh[128 + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                xz[i * 64 + lane] = 1.0f / (1.0f + __expf(-(g0[i] + biz)));
+                xh[i * 64 + lane] = g1[i] + bhn;
+            }
+        } else {
+            eh_load_frag(bf, a.w_ih + (size_t)(wr) * 64 + hh * 32);       eh_mma64(g0, am, bf);
+            eh_load_frag(bf, a.w_hh + (size_t)(wr) * 64 + hh * 32);       eh_mma64(g0, ah, bf);
+            eh_load_frag(bf, a.w_ih + (size_t)(128 + wr) * 64 + hh * 32); eh_mma64(g1, am, bf);
+        }
+        __syncthreads();
+        if (part == 0) {
+            const float bir = a.b_ih[col] + a.b_hh[col], bin = a.b_ih[128 + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rr = eh_crow(i, lane);
+                float zg = xz[i * 64 + lane], hn = xh[i * 64 + lane];
+                float rg = 1.0f / (1.0f + __expf(-(g0[i] + bir)));
+                float ng = tanhf((g1[i] + bin) + rg * hn);
+                float hv = hp[rr * EH_TP + col];
+                float o = (1.0f - zg) * ng + zg * hv;
+                ht[rr * EH_TP + col] = o;
+                if (rr < rows) a.hnew[(size_t)(row0 + rr) * 64 + col] = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase E: context pre-activation column sums
+    {
+        eh_frag af;
+        eh_load_frag_lds(af, ht, r, hh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nt = wave * 2 + j;
+            eh_frag bf;
+            eh_load_frag(bf, a.cw0 + (size_t)(nt * 32 + r) * 128 + hh * 32);
+            f32x16 acc = eh_zero16();
+            eh_mma64(acc, af, bf);
+            const int col = nt * 32 + r;
+            const float cb = a.cbias[(size_t)g * 256 + col];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = eh_silu(acc[i] + cb);
+                sum += (eh_crow(i, lane) < rows) ? v : 0.f;
+            }
+            sum += __shfl_xor(sum, 32);
+            if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // tail input of the active nodes: [h + ctx | emb_t(x_t) | emb_0(x_0) | emb_sel[1]]  (layers.py:377)
 // compact rows in active-node order; one wave per node tile (local index k of graph g).
 // --------------------------------------------------------------------------------------------
@@ -655,34 +882,19 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B), dim3(256), 0, s, *L, *P, l, lp, w.part, w.te, t_shared, w.ctx,
                            w.qbias, ldq, w.obias0, w.obias1, w.cbias));
         if (l == P->num_layers) break;
-        const int h = P->heads[l], H = h * 64;
-        // qt = Mcat h + qbias_g
-        eh_gemm_desc d = {};
-        d.A = hcur; d.lda = 64; d.K1 = 64; d.W = lp.Mcat; d.K = 64; d.N = H; d.gbias0 = w.qbias; d.ldg = ldq;
-        d.Y = w.Qt; d.ldy = H; d.act = 0;
-        d.tile_graph = L->tile_graph; d.tile_row0 = L->tile_row0; d.tile_rows = L->tile_rows; d.num_tiles = NT;
-        d.prof_id = EH_K_GEMM_QT;
-        int rc = eh_launch_gemm(d, s);
-        if (rc != EDGEHIP_OK) return rc;
-        dim3 ag((Nn + 3) / 4);
+        const int h = P->heads[l];
+        eh_layer_args la = {};
+        la.adj = adj; la.hprev = hcur; la.deg = deg;
+        la.Mcat = lp.Mcat; la.qbias = w.qbias; la.ldq = ldq;
+        la.Ocat = folded + fm.layer[l].Ocat; la.obias0 = w.obias0; la.obias1 = w.obias1;
+        la.w_ih = P->gru_w_ih; la.w_hh = P->gru_w_hh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
+        la.cw0 = P->context_w0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attention<8>, ag, dim3(256), 0, s, *L, adj, hcur, w.Qt, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attention<4>, ag, dim3(256), 0, s, *L, adj, hcur, w.Qt, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attention<2>, ag, dim3(256), 0, s, *L, adj, hcur, w.Qt, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attention<1>, ag, dim3(256), 0, s, *L, adj, hcur, w.Qt, w.Z)); break;
+            case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
+            case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(256), 0, s, *L, la)); break;
+            case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<2>, dim3(NT), dim3(256), 0, s, *L, la)); break;
+            default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<1>, dim3(NT), dim3(256), 0, s, *L, la)); break;
         }
-        // conv = silu(Ocat [z | h] + obias0_g + [deg>0] obias1_g)
-        eh_gemm_desc o = {};
-        o.A = w.Z; o.lda = H; o.A2 = hcur; o.lda2 = 64; o.K1 = H; o.W = folded + fm.layer[l].Ocat; o.K = H + 64;
-        o.N = 64; o.gbias0 = w.obias0; o.gbias1 = w.obias1; o.rowflag = deg; o.ldg = 64; o.Y = w.Mb; o.ldy = 64;
-        o.act = 1;
-        o.tile_graph = L->tile_graph; o.tile_row0 = L->tile_row0; o.tile_rows = L->tile_rows; o.num_tiles = NT;
-        o.prof_id = EH_K_GEMM_OUT;
-        rc = eh_launch_gemm(o, s);
-        if (rc != EDGEHIP_OK) return rc;
-        EH_PROF(EH_K_GRU, s, hipLaunchKernelGGL(k_gru, dim3(tile_blocks), dim3(256), 0, s, *L, P->gru_w_ih, P->gru_w_hh, P->gru_b_ih,
-                           P->gru_b_hh, w.Mb, hcur, hnext));
-        EH_PROF(EH_K_CTX, s, hipLaunchKernelGGL(k_ctx, dim3(tile_blocks), dim3(256), 0, s, *L, P->context_w0, w.cbias, hnext, w.part));
         float* t = hcur; hcur = hnext; hnext = t;
     }
     if (h_out) {
