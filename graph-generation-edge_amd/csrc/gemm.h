@@ -58,11 +58,23 @@ __device__ static inline void eh_load_frag_lds(eh_frag& f, const float* tile, in
     for (int i = 0; i < 8; ++i) f.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
 }
 
+// ---- weights in fragment order (k_pack_w in gnn.hip) ---------------------------------------------
+// tile (nt, kc) of a packed [N][K] matrix starts at ((nt * K/64) + kc) * 2048 floats; a fragment is
+// eight fully coalesced 1-KiB loads.
+__device__ static inline void eh_load_frag_packed(eh_frag& f, const float* __restrict__ packed, int KC, int nt, int kc,
+                                                  int lane) {
+    const float* p = packed + ((size_t)(nt * KC + kc) * 2048) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = *reinterpret_cast<const f32x4*>(p + i * 256);
+}
+
 // Generic linear-layer descriptor (see gemm.hip)
 struct eh_gemm_desc {
     const float* A; int lda;            // A rows, k < K1
+    const int32_t* arow_index;          // optional gather: logical row i reads A row arow_index[i] (packed path)
     const float* A2; int lda2; int K1;  // optional second source for k >= K1 (concat along K); K1 % 64 == 0
     const float* W; int K; int N;       // W [N,K] row-major, K % 64 == 0, N % 32 == 0
+    int w_packed;                       // W is in fragment order (eh_load_frag_packed): no LDS staging
     const float* bias;                  // [N] or null
     const float* gbias0;                // [B,ldg] per-graph bias or null
     const float* gbias1;                // [B,ldg] per-graph bias applied where rowflag[row] > 0, or null

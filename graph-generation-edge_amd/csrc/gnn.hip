@@ -16,10 +16,13 @@
 // --------------------------------------------------------------------------------------------
 // folded-weight buffer layout (floats)
 // --------------------------------------------------------------------------------------------
-struct eh_fold_layer { size_t Mcat, Mtcat, mbcat, Ocat, Vbbar, bvbar, Vsum; };
+struct eh_fold_layer { size_t Mcat, Mtcat, mbcat, Ocat, Vbbar, bvbar, Vsum, pMcat, pOcat; };
 struct eh_fold_map {
     size_t nin_at, nin_a0, nin_as;   // [64], [64], [2][64]
     size_t W4f, b4f;                 // [128,128], [128]
+    // the same matrices re-laid in MFMA fragment order (eh_pack_index): one 1-KiB coalesced load per
+    // fragment instruction instead of 64 lines
+    size_t pWih, pWhh, pCw0, pNo0, pNo2, pW4f, pFw2;
     eh_fold_layer layer[EDGEHIP_MAX_LAYERS];
     size_t total;
 };
@@ -30,11 +33,14 @@ static eh_fold_map eh_make_fold_map(const edgehip_gnn_params* P) {
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
     m.nin_at = take(64); m.nin_a0 = take(64); m.nin_as = take(128);
     m.W4f = take(128 * 128); m.b4f = take(128);
+    m.pWih = take(192 * 64); m.pWhh = take(192 * 64); m.pCw0 = take(256 * 64);
+    m.pNo0 = take(128 * 256); m.pNo2 = take(128 * 128); m.pW4f = take(128 * 128); m.pFw2 = take(64 * 128);
     for (int l = 0; l < P->num_layers && l < EDGEHIP_MAX_LAYERS; ++l) {
         size_t H = (size_t)P->heads[l] * EH_D;
         m.layer[l].Mcat = take(H * 64); m.layer[l].Mtcat = take(H * 64); m.layer[l].mbcat = take(H);
         m.layer[l].Ocat = take(64 * (H + 64)); m.layer[l].Vbbar = take(64 * 64); m.layer[l].bvbar = take(64);
         m.layer[l].Vsum = take(64 * 64);
+        m.layer[l].pMcat = take(H * 64); m.layer[l].pOcat = take(64 * (H + 64));
     }
     m.total = o;
     return m;
@@ -129,6 +135,26 @@ __global__ __launch_bounds__(128) void k_fold_tail(const float* __restrict__ f0,
     if (j == 0) b4f[i] = sb;
 }
 
+// Pack W[N][ldw] (columns col0 .. col0+K) into fragment order: tile (nt, kc) holds 32 rows x 64 k as
+// [i = 0..7][lane = 0..63][e = 0..3] = W[nt*32 + (lane&31)][col0 + kc*64 + (lane>>5)*32 + 4i + e].
+__global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, int ldw, int col0, int N, int K,
+                                                float* __restrict__ out) {
+    int idx = blockIdx.x * 256 + threadIdx.x;          // one float4 per thread
+    int total = N * K / 4;
+    if (idx >= total) return;
+    int lane = idx & 63, i = (idx >> 6) & 7, tile = idx >> 9;
+    int KC = K / 64;
+    int nt = tile / KC, kc = tile % KC;
+    const float* src = W + (size_t)(nt * 32 + (lane & 31)) * ldw + col0 + kc * 64 + (lane >> 5) * 32 + 4 * i;
+    f32x4 v;
+    v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+    *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = v;
+}
+
+static void eh_pack(const float* W, int ldw, int col0, int N, int K, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_w, dim3((N * K / 4 + 255) / 256), dim3(256), 0, s, W, ldw, col0, N, K, out);
+}
+
 extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, void* stream) {
     int rc = eh_check_params(P);
     if (rc != EDGEHIP_OK) return rc;
@@ -145,7 +171,16 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
         hipLaunchKernelGGL(k_fold_out, dim3(64), dim3(64), 0, s, h, P->value_w[l], P->value_b[l], P->skip_w[l],
                            folded + m.layer[l].Ocat, folded + m.layer[l].Vbbar, folded + m.layer[l].bvbar,
                            folded + m.layer[l].Vsum);
+        eh_pack(folded + m.layer[l].Mcat, 64, 0, h * 64, 64, folded + m.layer[l].pMcat, s);
+        eh_pack(folded + m.layer[l].Ocat, h * 64 + 64, 0, 64, h * 64 + 64, folded + m.layer[l].pOcat, s);
     }
+    eh_pack(P->gru_w_ih, 64, 0, 192, 64, folded + m.pWih, s);
+    eh_pack(P->gru_w_hh, 64, 0, 192, 64, folded + m.pWhh, s);
+    eh_pack(P->context_w0, 128, 0, 256, 64, folded + m.pCw0, s);
+    eh_pack(P->node_out_w0, 256, 0, 128, 256, folded + m.pNo0, s);
+    eh_pack(P->node_out_w2, 128, 0, 128, 128, folded + m.pNo2, s);
+    eh_pack(folded + m.W4f, 128, 0, 128, 128, folded + m.pW4f, s);
+    eh_pack(P->final_w2, 128, 0, 64, 128, folded + m.pFw2, s);
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -156,7 +191,7 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
 struct eh_ws {
     float *hA, *hB, *Qt, *Z, *Mb, *part, *te, *ctx, *qbias, *obias0, *obias1, *cbias, *Xact, *U1, *U2;
     // step-level scratch
-    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *deg2;
+    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *deg2, *heavy_nodes, *heavy_slot, *heavy_count;
     int64_t* aptr;
     uint8_t* flags;
     float *node_repr, *tile_partial;
@@ -186,6 +221,7 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.U1 = (float*)take(NnP * 128 * 4); w.U2 = (float*)take(NnP * 128 * 4);
     w.deg = (int32_t*)take(NnP * 4); w.deg2 = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
+    w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4); w.heavy_count = (int32_t*)take(256);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
     w.tptr = (int32_t*)take((B + 2) * 4); w.t_graph = (int32_t*)take((B + 1) * 4);
     w.aptr = (int64_t*)take((B + 2) * 8);
@@ -374,88 +410,116 @@ __device__ static inline float eh_group8_sum(float v) {
     return v;
 }
 
-// One target node: walk the set bits of its bit-matrix row (wave-uniform iterator, ascending j),
-// keep U neighbours per slot in flight, online softmax.  q: this lane's 8 channels of qt for its head.
-// out: this lane's 8 channels of z = sum_j alpha_j h_j (valid in every slot after the merge).
-template <int HEADS>
-__device__ static inline void eh_attend(const uint32_t* __restrict__ rowp, int stride, int node0, int self_node,
-                                        const float* __restrict__ hsrc, const float (&q)[8], int lane, float (&out)[8]) {
+// One target node (or a word range of its row).  Per 64-word chunk of the bit-matrix row:
+//   1. decode: every lane holds one word; popcount + wave prefix sum give each lane its place in an
+//      ascending neighbour-id list in LDS (vector ops - a scalar pop per neighbour cost ~25 SALU each);
+//   2. gather: rows of h are fetched ONCE per neighbour, 16 lanes x 16 B per row, RB rows per step, the
+//      next step's loads in flight while the current one is consumed, and staged in a small LDS ring
+//      (the head groups of a wave all need the same row: reading it back from LDS is a broadcast);
+//   3. online softmax over the step: scores (pass 1), then the weighted sum (pass 2), both from LDS.
+// q: this lane's 8 channels of qt for its head.  Returns the raw state (m, l, acc) so partial walks of
+// one row can be merged; eh_attend normalises.
+#define EH_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int HEADS, int SUBW, int RB>
+__device__ static inline void eh_attend_raw(const uint32_t* __restrict__ rowp, int w_begin, int w_end,
+                                            uint32_t first_word, int node0, const float* __restrict__ hsrc,
+                                            const float (&q)[8], int lane, float (&acc)[8], float& m, float& lsum,
+                                            int* __restrict__ ids, float* __restrict__ ring) {
     constexpr int NSLOT = 8 / HEADS;
-    constexpr int U = 4;                 // neighbours in flight per slot: hubs are a latency chain otherwise
+    constexpr int UP = (RB + NSLOT - 1) / NSLOT;     // neighbours per lane and step
+    constexpr int NL = RB / 4;                       // 1-KiB load instructions per step
+    static_assert(RB % 4 == 0 && RB <= 8, "ring sized for at most 8 rows");
     const int grp = lane >> 3, c = lane & 7;
     const int slot = grp / HEADS;
-    float acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
-    int w0 = -64;
-    uint32_t word = 0u, wv = 0u;
-    unsigned long long nz = 0ull;
-    int jbase = 0;
-    bool done = false;
-    auto next = [&]() -> int {
-        while (wv == 0u) {
-            if (nz == 0ull) {
-                if (done || w0 + 64 >= stride) { done = true; return -1; }
-                w0 += 64;
-                word = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
-                nz = __ballot(word != 0u);
-                continue;
-            }
-            int src = __ffsll((long long)nz) - 1;
-            nz &= nz - 1;
-            wv = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
-            jbase = node0 + (w0 + src) * 32;
+    m = -INFINITY; lsum = 0.f;
+
+    auto issue = [&](int n, int total, f32x4 (&st)[NL]) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            int rr = n + k * 4 + (lane >> 4);
+            int id = ids[rr < total ? rr : total - 1];
+            st[k] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)id * 64 + (lane & 15) * 4);
         }
-        int j = jbase + __ffs((int)wv) - 1;
-        wv &= wv - 1;
-        return j;
     };
-    while (true) {
-        int myj[U];
-        int first = -1;
+    auto step = [&](const f32x4 (&st)[NL], int n0, int total) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            myj[u] = -1;
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                int j = next();
-                if (u == 0 && s == 0) first = j;
-                if (slot == s) myj[u] = j;
-            }
-        }
-        if (first < 0) break;
-        f32x4 xa[U], xb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const f32x4* xp = reinterpret_cast<const f32x4*>(hsrc + (size_t)(myj[u] >= 0 ? myj[u] : self_node) * 64 + c * 8);
-            xa[u] = xp[0]; xb[u] = xp[1];
-        }
-        float sc[U];
+        for (int k = 0; k < NL; ++k)
+            *reinterpret_cast<f32x4*>(ring + (k * 4 + (lane >> 4)) * 64 + (lane & 15) * 4) = st[k];
+        EH_LDS_SYNC();
+        float sc[UP];
         float mn = m;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UP; ++u) {
+            const int rr = u * NSLOT + slot;
+            const bool valid = rr < RB && n0 + rr < total;
+            const float* xp = ring + (rr < RB ? rr : 0) * 64 + c * 8;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
             float t = 0.f;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) t += q[d] * xa[u][d] + q[4 + d] * xb[u][d];
+            for (int d = 0; d < 4; ++d) t += q[d] * x0[d] + q[4 + d] * x1[d];
             t = eh_group8_sum(t);
-            sc[u] = (myj[u] >= 0) ? t : -INFINITY;
+            sc[u] = valid ? t : -INFINITY;
             mn = fmaxf(mn, sc[u]);
         }
-        if (mn > -INFINITY) {           // this slot saw at least one neighbour so far
-            float resc = __expf(m - mn);      // m = -inf before the first neighbour: exp(-inf) = 0
-            float p[U], ps = 0.f;
+        asm volatile("" ::: "memory");        // pass 2 re-reads the rows from LDS instead of keeping 8 of them in VGPRs
+        if (mn > -INFINITY) {                 // this slot has seen at least one neighbour
+            const float resc = __expf(m - mn);      // m = -inf before the first neighbour: exp(-inf) = 0
+            float ps = 0.f;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { p[u] = __expf(sc[u] - mn); ps += p[u]; }
+            for (int u = 0; u < UP; ++u) { sc[u] = __expf(sc[u] - mn); ps += sc[u]; }
             lsum = lsum * resc + ps;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                float a0 = acc[d] * resc, a1 = acc[4 + d] * resc;
+            for (int d = 0; d < 8; ++d) acc[d] *= resc;
 #pragma unroll
-                for (int u = 0; u < U; ++u) { a0 += p[u] * xa[u][d]; a1 += p[u] * xb[u][d]; }
-                acc[d] = a0; acc[4 + d] = a1;
+            for (int u = 0; u < UP; ++u) {
+                const int rr = u * NSLOT + slot;
+                const float* xp = ring + (rr < RB ? rr : 0) * 64 + c * 8;
+                f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { acc[d] += sc[u] * x0[d]; acc[4 + d] += sc[u] * x1[d]; }
             }
             m = mn;
+        }
+        asm volatile("" ::: "memory");
+    };
+
+    for (int w0 = w_begin; w0 < w_end; w0 += 64) {
+        const uint32_t word = (w0 == w_begin) ? first_word : ((w0 + lane < w_end) ? rowp[w0 + lane] : 0u);
+        const unsigned long long nzmask = __ballot(word != 0u);
+        if (nzmask == 0ull) continue;
+#pragma unroll 1
+        for (int sb = 0; sb < 64; sb += SUBW) {
+            if (SUBW < 64 && ((nzmask >> sb) & ((1ull << (SUBW & 63)) - 1ull)) == 0ull) continue;
+            uint32_t w = (SUBW == 64 || (lane >= sb && lane < sb + SUBW)) ? word : 0u;
+            const int cnt = __popc(w);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int pos = incl - cnt;
+            const int jb = node0 + (w0 + lane) * 32;
+            while (w) { ids[pos++] = jb + __ffs((int)w) - 1; w &= w - 1; }
+            EH_LDS_SYNC();
+            // steps of RB neighbours, two register sets ping-pong
+            f32x4 sa[NL], sb2[NL];
+            const int nsteps = (total + RB - 1) / RB;
+            issue(0, total, sa);
+#pragma unroll 1
+            for (int g = 0; g < nsteps; g += 2) {
+                if (g + 1 < nsteps) issue((g + 1) * RB, total, sb2);
+                step(sa, g * RB, total);
+                if (g + 1 >= nsteps) break;
+                if (g + 2 < nsteps) issue((g + 2) * RB, total, sa);
+                step(sb2, (g + 1) * RB, total);
+            }
+            EH_LDS_SYNC();
         }
     }
     if (NSLOT > 1) {
@@ -473,42 +537,6 @@ __device__ static inline void eh_attend(const uint32_t* __restrict__ rowp, int s
             }
             m = mn;
         }
-    }
-    float inv = 1.0f / (lsum + 1e-16f);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) out[d] = acc[d] * inv;
-}
-
-template <int HEADS>
-__global__ __launch_bounds__(256) void k_attention(edgehip_layout L, const uint32_t* __restrict__ adj,
-                                                   const float* __restrict__ hsrc, const float* __restrict__ Qt,
-                                                   float* __restrict__ Z) {
-    constexpr int H = HEADS * 64;
-    const int lane = threadIdx.x & 63;
-    // wave-uniform by construction; readfirstlane tells the compiler, so the row walk stays in SGPRs /
-    // scalar branches instead of exec-masked vector code
-    const int node = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (node >= L.num_nodes) return;
-    const int b = L.node_graph[node];
-    const int node0 = L.node_ptr[b];
-    const int stride = L.adj_stride[b];
-    const uint32_t* rowp = adj + L.adj_ptr[b] + (int64_t)(node - node0) * stride;
-    const int grp = lane >> 3, c = lane & 7;
-    const int head = grp % HEADS, slot = grp / HEADS;
-    float q[8], z[8];
-    {
-        const f32x4* qp = reinterpret_cast<const f32x4*>(Qt + (size_t)node * H + head * 64 + c * 8);
-        f32x4 q0 = qp[0], q1 = qp[1];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
-    }
-    eh_attend<HEADS>(rowp, stride, node0, node, hsrc, q, lane, z);
-    if (slot == 0) {
-        f32x4 o0, o1;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { o0[d] = z[d]; o1[d] = z[4 + d]; }
-        f32x4* zp = reinterpret_cast<f32x4*>(Z + (size_t)node * H + head * 64 + c * 8);
-        zp[0] = o0; zp[1] = o1;
     }
 }
 
@@ -550,9 +578,9 @@ __global__ __launch_bounds__(256) void k_gru(edgehip_layout L, const float* __re
             int rr = eh_crow(i, lane);
             if (rr < rows) {
                 size_t o = (size_t)(row0 + rr) * 64 + col;
-                float rg = 1.0f / (1.0f + __expf(-(ar[i] + bir)));
-                float zg = 1.0f / (1.0f + __expf(-(az[i] + biz)));
-                float ng = tanhf((ain[i] + bin) + rg * (ahn[i] + bhn));
+                float rg = eh_sigmoid_fast(((ar[i] + bir)));
+                float zg = eh_sigmoid_fast(((az[i] + biz)));
+                float ng = eh_tanh_fast((ain[i] + bin) + rg * (ahn[i] + bhn));
                 float hp = hprev[o];
                 hnew[o] = (1.0f - zg) * ng + zg * hp;
             }
@@ -593,11 +621,100 @@ __global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __re
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 int rr = eh_crow(i, lane);
-                float v = eh_silu(acc[i] + cb);
+                float v = eh_silu_fast(acc[i] + cb);
                 s += (rr < rows) ? v : 0.f;
             }
             s += __shfl_xor(s, 32);
             if (live && lane < 32) part[(size_t)tile * 256 + col] = s;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Heavy rows.  Degrees are skewed (polblogs: mean 27, max ~350): a hub walked by one wave is a serial
+// chain that idles the rest of its tile.  Nodes with more than EH_HEAVY_DEG neighbours are listed once
+// per step (k_heavy_list) and, per layer, get a whole block (k_attn_heavy): qt by a 64 x 64h GEMV,
+// the bit row split into four word ranges (one per wave), partial softmax states merged through LDS,
+// z written to zheavy[slot].  The fused layer kernel copies that z instead of walking the row.
+// --------------------------------------------------------------------------------------------
+#define EH_HEAVY_DEG 40
+
+__global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, int32_t* __restrict__ counter,
+                                                    int32_t* __restrict__ heavy_nodes, int32_t* __restrict__ heavy_slot) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nn) return;
+    int slot = -1;
+    if (deg[i] > EH_HEAVY_DEG) { slot = atomicAdd(counter, 1); heavy_nodes[slot] = i; }
+    heavy_slot[i] = slot;    // list order is arbitrary; every slot is computed independently of the others
+}
+
+// per-graph bias of the gathered heavy rows: qheavy[i][o] += qbias[graph(heavy_nodes[i])][o]
+__global__ __launch_bounds__(256) void k_heavy_qbias(edgehip_layout L, int H, const float* __restrict__ qbias, int ldq,
+                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
+                                                     float* __restrict__ qheavy) {
+    const int64_t total = (int64_t)(*counter) * H;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int i = (int)(e / H), o = (int)(e % H);
+        qheavy[e] += qbias[(size_t)L.node_graph[heavy_nodes[i]] * ldq + o];
+    }
+}
+
+template <int HEADS>
+__global__ __launch_bounds__(256, 3) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
+                                                       const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
+                                                       const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
+                                                       float* __restrict__ zheavy) {
+    constexpr int H = HEADS * 64;
+    __shared__ float ms[4][8], ls[4][8];
+    __shared__ __attribute__((aligned(16))) float accs[4][64][8];
+    __shared__ int idl[4][512];                                        // neighbour ids of one 16-word sub-chunk
+    __shared__ __attribute__((aligned(16))) float rng[4][8 * 64];      // staged rows of h
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int nheavy = *counter;
+    for (int idx = blockIdx.x; idx < nheavy; idx += gridDim.x) {
+        const int node = heavy_nodes[idx];
+        const int g = L.node_graph[node];
+        const int node0 = L.node_ptr[g];
+        const int stride = L.adj_stride[g];
+        const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
+        __syncthreads();                       // previous iteration's LDS is consumed
+        const int grp = lane >> 3, c = lane & 7;
+        const int head = grp % HEADS;
+        float q[8], acc[8], m, lsum;
+        {
+            const f32x4* qp = reinterpret_cast<const f32x4*>(qheavy + (size_t)idx * H + head * 64 + c * 8);
+            f32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
+        }
+        const int per = (stride + 3) / 4;
+        const int wb = wave * per, we = (wb + per < stride) ? wb + per : stride;
+        const uint32_t fw = (wb + lane < we) ? rowp[wb + lane] : 0u;
+        eh_attend_raw<HEADS, 16, 8>(rowp, wb, we, fw, node0, hsrc, q, lane, acc, m, lsum, idl[wave], rng[wave]);
+        if (c == 0 && grp < HEADS) { ms[wave][head] = m; ls[wave][head] = lsum; }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) accs[wave][lane][d] = acc[d];
+        __syncthreads();
+        if (wave == 0 && grp < HEADS) {         // fixed merge order: wave 0..3
+            float M = fmaxf(fmaxf(ms[0][head], ms[1][head]), fmaxf(ms[2][head], ms[3][head]));
+            float Lsum = 0.f, out[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) out[d] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float mw = ms[w][head];
+                float sc = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                Lsum += ls[w][head] * sc;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) out[d] += accs[w][lane][d] * sc;
+            }
+            float inv = 1.0f / (Lsum + 1e-16f);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { o0[d] = out[d] * inv; o1[d] = out[4 + d] * inv; }
+            f32x4* zp = reinterpret_cast<f32x4*>(zheavy + (size_t)idx * H + head * 64 + c * 8);
+            zp[0] = o0; zp[1] = o1;
         }
     }
 }
@@ -618,8 +735,23 @@ struct eh_layer_args {
     const float* Ocat; const float* obias0; const float* obias1;
     const float *w_ih, *w_hh, *b_ih, *b_hh;
     const float* cw0; const float* cbias;
+    const int32_t* heavy_slot; const float* zheavy;   // rows walked by k_attn_heavy (slot >= 0)
     float* hnew; float* part;
 };
+
+#ifdef EH_STAMP
+// diagnostic build only (make STAMP=1): per-phase cycle sums of wave 0 of every block
+__device__ unsigned long long eh_dbg[16];
+#define EH_STAMP_AT(k) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&eh_dbg[k], t_ - t_prev); t_prev = t_; } } while (0)
+extern "C" int edgehip_debug_read(unsigned long long* out_host, int reset) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(eh_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(eh_dbg), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define EH_STAMP_AT(k) do { } while (0)
+#endif
 
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
 #define EH_TSZ (32 * EH_TP)
@@ -628,18 +760,29 @@ template <int HEADS>
 __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a) {
     constexpr int H = HEADS * 64, QP = H + 4;
     constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ];
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG];
     float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
     float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
     float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
     float* mt = lds + 4 * EH_TSZ;       // [32][68]   conv
     float* ht = lds + 5 * EH_TSZ;       // [32][68]   h'
     float* hp = lds + R1;               // [32][68]   h (layer input / GRU hidden)
+    int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [4 waves][8 targets][EH_HEAVY_DEG] neighbour ids
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so XCD x gets the
+    // contiguous tile range [x*NT/8, (x+1)*NT/8) = a handful of graphs whose h rows (313 KB each) stay in
+    // that XCD's 4 MB L2 for the neighbour gathers.  Affinity only; any placement is correct.
+    int tile;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
+        tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    }
     const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
     const int r = lane & 31, hh = lane >> 5;
+#ifdef EH_STAMP
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- phase 0: h tile -> LDS (full-line loads)
 #pragma unroll
@@ -650,6 +793,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             *reinterpret_cast<const f32x4*>(a.hprev + (size_t)src * 64 + c4 * 4);
     }
     __syncthreads();
+    EH_STAMP_AT(0);
 
     // ---- phase A: qt
     {
@@ -657,7 +801,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         eh_load_frag_lds(af, hp, r, hh);
         for (int nt = wave; nt < 2 * HEADS; nt += 4) {
             eh_frag bf;
-            eh_load_frag(bf, a.Mcat + (size_t)(nt * 32 + r) * 64 + hh * 32);
+            eh_load_frag_packed(bf, a.Mcat, 1, nt, 0, lane);
             f32x16 acc = eh_zero16();
             eh_mma64(acc, af, bf);
             const int col = nt * 32 + r;
@@ -667,36 +811,132 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     __syncthreads();
+    EH_STAMP_AT(1);
 
-    // ---- phase B: attention, 8 targets per wave, z overwrites qt
+    // ---- phase B: attention of the light rows, z overwrites qt.
+    // One 8-lane group per TARGET: a wave advances its 8 targets together, one neighbour each per
+    // iteration, every group gathering its own 256-byte row (no redundant loads), the next iteration's
+    // rows in flight.  Lane (group, c) keeps channels 8c..8c+7 of qt and of the running sum for all heads.
     {
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
         const uint32_t* gadj = a.adj + L.adj_ptr[g];
         const int grp = lane >> 3, c = lane & 7;
-        const int head = grp % HEADS, slot = grp / HEADS;
+        int* myids = idl + wave * (8 * EH_HEAVY_DEG);
+        const bool mine8 = lane < 8 && wave * 8 + lane < rows;
+        const int hs8 = mine8 ? a.heavy_slot[row0 + wave * 8 + lane] : -1;
+        const int dg8 = mine8 ? a.deg[row0 + wave * 8 + lane] : 0;
+        // (a) bit rows of the 8 targets, all loads in flight before the first is decoded
+        uint32_t fw[8];
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int rr = wave * 8 + k;
-            if (rr >= rows) break;
-            const int node = row0 + rr;
-            float* qp = qz + rr * QP + head * 64 + c * 8;
-            float q[8], z[8];
-            {
-                f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+            const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
+            fw[k] = (need && lane < stride) ? gadj[(int64_t)(row0 + wave * 8 + k - node0) * stride + lane] : 0u;
+        }
+        // (b) decode each row into an ascending neighbour-id list in LDS (popcount + wave prefix sum)
+        int mydeg = 0;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
-            }
-            eh_attend<HEADS>(gadj + (int64_t)(node - node0) * stride, stride, node0, node, a.hprev, q, lane, z);
-            if (slot == 0) {
-                f32x4 o0, o1;
+        for (int k = 0; k < 8; ++k) {
+            const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
+            if (need) {
+                int base = 0;
+                const uint32_t* rowp = gadj + (int64_t)(row0 + wave * 8 + k - node0) * stride;
+                for (int w0 = 0; w0 < stride; w0 += 64) {
+                    uint32_t w = (w0 == 0) ? fw[k] : ((w0 + lane < stride) ? rowp[w0 + lane] : 0u);
+                    const int cnt = __popc(w);
+                    int incl = cnt;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) { o0[d] = z[d]; o1[d] = z[4 + d]; }
-                *reinterpret_cast<f32x4*>(qp) = o0;
-                *reinterpret_cast<f32x4*>(qp + 4) = o1;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        int t = __shfl_up(incl, d);
+                        if (lane >= d) incl += t;
+                    }
+                    int pos = base + incl - cnt;
+                    const int jb = node0 + (w0 + lane) * 32;
+                    while (w) {
+                        if (pos < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + pos] = jb + __ffs((int)w) - 1;
+                        ++pos;
+                        w &= w - 1;
+                    }
+                    base += __builtin_amdgcn_readlane(incl, 63);
+                }
+                if (grp == k) mydeg = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
             }
+        }
+        EH_LDS_SYNC();
+        // (c) the 8 targets advance together
+        const int trow = wave * 8 + grp;
+        const int self = row0 + (trow < rows ? trow : rows - 1);
+        float* qrow = qz + trow * QP + c * 8;
+        float q[HEADS][8], acc[HEADS][8], mh[HEADS], lh[HEADS];
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            f32x4 q0 = *reinterpret_cast<const f32x4*>(qrow + h * 64), q1 = *reinterpret_cast<const f32x4*>(qrow + h * 64 + 4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { q[h][d] = q0[d]; q[h][4 + d] = q1[d]; acc[h][d] = 0.f; acc[h][4 + d] = 0.f; }
+            mh[h] = -1e30f; lh[h] = 0.f;      // finite floor: exp(-1e30 - x) = 0 and never inf - inf
+        }
+        const int* lst = myids + grp * EH_HEAVY_DEG;
+        auto loadx = [&](int i, f32x4& x0, f32x4& x1) {
+            const int id = (i < mydeg) ? lst[i] : self;
+            const f32x4* xp = reinterpret_cast<const f32x4*>(a.hprev + (size_t)id * 64 + c * 8);
+            x0 = xp[0]; x1 = xp[1];
+        };
+        auto update = [&](bool valid, const f32x4& x0, const f32x4& x1) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                float t = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) t += q[h][d] * x0[d] + q[h][4 + d] * x1[d];
+                t = eh_group8_sum(t);
+                t = valid ? t : -INFINITY;
+                const float mn = fmaxf(mh[h], t);
+                const float resc = __expf(mh[h] - mn);
+                const float p = __expf(t - mn);
+                lh[h] = lh[h] * resc + p;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[h][d] = acc[h][d] * resc + p * x0[d];
+                    acc[h][4 + d] = acc[h][4 + d] * resc + p * x1[d];
+                }
+                mh[h] = mn;
+            }
+        };
+        {
+            f32x4 xa0, xa1, xb0, xb1;
+            int it = 0;
+            if (__any(mydeg > 0)) {
+                loadx(0, xa0, xa1);
+                while (true) {
+                    loadx(it + 1, xb0, xb1);
+                    update(it < mydeg, xa0, xa1);
+                    ++it;
+                    if (!__any(it < mydeg)) break;
+                    loadx(it + 1, xa0, xa1);
+                    update(it < mydeg, xb0, xb1);
+                    ++it;
+                    if (!__any(it < mydeg)) break;
+                }
+            }
+        }
+        // (d) z -> LDS (heavy rows: the block-per-row kernel already computed it)
+        const int hslot = __shfl(hs8, grp);
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            f32x4 o0, o1;
+            if (hslot >= 0) {
+                const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + h * 64 + c * 8);
+                o0 = zp[0]; o1 = zp[1];
+            } else {
+                const float inv = 1.0f / (lh[h] + 1e-16f);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { o0[d] = acc[h][d] * inv; o1[d] = acc[h][4 + d] * inv; }
+            }
+            *reinterpret_cast<f32x4*>(qrow + h * 64) = o0;
+            *reinterpret_cast<f32x4*>(qrow + h * 64 + 4) = o1;
         }
     }
     __syncthreads();
+    EH_STAMP_AT(2);
 
     // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1); K chunks split over the waves
     {
@@ -710,12 +950,13 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             } else {
                 eh_load_frag_lds(af, hp, r, hh);
             }
-            eh_load_frag(bf, a.Ocat + (size_t)r * (H + 64) + ch * 64 + hh * 32);
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, 0, ch, lane);
             eh_mma64(acc0, af, bf);
-            eh_load_frag(bf, a.Ocat + (size_t)(32 + r) * (H + 64) + ch * 64 + hh * 32);
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, 1, ch, lane);
             eh_mma64(acc1, af, bf);
         }
         __syncthreads();                      // every wave is done reading qz
+        EH_STAMP_AT(3);
         float* mine = pt + wave * EH_TSZ;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -739,17 +980,18 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 int col = c0 + 4 * q4 + e;
                 float x = v[e] + a.obias0[(size_t)g * 64 + col];
                 if (hasnbr) x += a.obias1[(size_t)g * 64 + col];
-                v[e] = eh_silu(x);
+                v[e] = eh_silu_fast(x);
             }
             *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0 + 4 * q4) = v;
         }
     }
     __syncthreads();
+    EH_STAMP_AT(4);
 
     // ---- phase D: GRU.  wave = (column tile ct, gate part): part 0 -> r and i_n, part 1 -> z and h_n
     {
         const int ct = wave & 1, part = wave >> 1;
-        const int wr = ct * 32 + r, col = ct * 32 + r;
+        const int col = ct * 32 + r;
         eh_frag am, ah, bf;
         eh_load_frag_lds(am, mt, r, hh);
         eh_load_frag_lds(ah, hp, r, hh);
@@ -757,19 +999,19 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         float* xz = xg + (ct * 2 + 0) * 1024;
         float* xh = xg + (ct * 2 + 1) * 1024;
         if (part == 1) {
-            eh_load_frag(bf, a.w_ih + (size_t)(64 + wr) * 64 + hh * 32);  eh_mma64(g0, am, bf);
-            eh_load_frag(bf, a.w_hh + (size_t)(64 + wr) * 64 + hh * 32);  eh_mma64(g0, ah, bf);
-            eh_load_frag(bf, a.w_hh + (size_t)(128 + wr) * 64 + hh * 32); eh_mma64(g1, ah, bf);
+            eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane); eh_mma64(g0, am, bf);
+            eh_load_frag_packed(bf, a.w_hh, 1, 2 + ct, 0, lane); eh_mma64(g0, ah, bf);
+            eh_load_frag_packed(bf, a.w_hh, 1, 4 + ct, 0, lane); eh_mma64(g1, ah, bf);
             const float biz = a.b_ih[64 + col] + a.b_hh[64 + col], bhn = a.b_hh[128 + col];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                xz[i * 64 + lane] = 1.0f / (1.0f + __expf(-(g0[i] + biz)));
+                xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + biz)));
                 xh[i * 64 + lane] = g1[i] + bhn;
             }
         } else {
-            eh_load_frag(bf, a.w_ih + (size_t)(wr) * 64 + hh * 32);       eh_mma64(g0, am, bf);
-            eh_load_frag(bf, a.w_hh + (size_t)(wr) * 64 + hh * 32);       eh_mma64(g0, ah, bf);
-            eh_load_frag(bf, a.w_ih + (size_t)(128 + wr) * 64 + hh * 32); eh_mma64(g1, am, bf);
+            eh_load_frag_packed(bf, a.w_ih, 1, ct, 0, lane);     eh_mma64(g0, am, bf);
+            eh_load_frag_packed(bf, a.w_hh, 1, ct, 0, lane);     eh_mma64(g0, ah, bf);
+            eh_load_frag_packed(bf, a.w_ih, 1, 4 + ct, 0, lane); eh_mma64(g1, am, bf);
         }
         __syncthreads();
         if (part == 0) {
@@ -778,8 +1020,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             for (int i = 0; i < 16; ++i) {
                 int rr = eh_crow(i, lane);
                 float zg = xz[i * 64 + lane], hn = xh[i * 64 + lane];
-                float rg = 1.0f / (1.0f + __expf(-(g0[i] + bir)));
-                float ng = tanhf((g1[i] + bin) + rg * hn);
+                float rg = eh_sigmoid_fast(((g0[i] + bir)));
+                float ng = eh_tanh_fast((g1[i] + bin) + rg * hn);
                 float hv = hp[rr * EH_TP + col];
                 float o = (1.0f - zg) * ng + zg * hv;
                 ht[rr * EH_TP + col] = o;
@@ -788,6 +1030,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     __syncthreads();
+    EH_STAMP_AT(5);
 
     // ---- phase E: context pre-activation column sums
     {
@@ -797,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         for (int j = 0; j < 2; ++j) {
             const int nt = wave * 2 + j;
             eh_frag bf;
-            eh_load_frag(bf, a.cw0 + (size_t)(nt * 32 + r) * 128 + hh * 32);
+            eh_load_frag_packed(bf, a.cw0, 1, nt, 0, lane);
             f32x16 acc = eh_zero16();
             eh_mma64(acc, af, bf);
             const int col = nt * 32 + r;
@@ -805,13 +1048,14 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float v = eh_silu(acc[i] + cb);
+                float v = eh_silu_fast(acc[i] + cb);
                 sum += (eh_crow(i, lane) < rows) ? v : 0.f;
             }
             sum += __shfl_xor(sum, 32);
             if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
         }
     }
+    EH_STAMP_AT(6);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -869,6 +1113,9 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     EH_PROF(EH_K_TIME_EMBED, s, hipLaunchKernelGGL(k_time_embed, dim3(t_shared ? 1 : B), dim3(256), 0, s, *P, t_graph, w.te));
     EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_node_in, dim3(tile_blocks), dim3(256), 0, s, *L, P->max_degree, folded + fm.nin_at,
                        folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, w.hA, w.part));
+    (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
+    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_heavy_list, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, deg, w.heavy_count, w.heavy_nodes,
+                       w.heavy_slot));
     float* hcur = w.hA;
     float* hnext = w.hB;
     for (int l = 0; l <= P->num_layers; ++l) {
@@ -885,10 +1132,28 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         const int h = P->heads[l];
         eh_layer_args la = {};
         la.adj = adj; la.hprev = hcur; la.deg = deg;
-        la.Mcat = lp.Mcat; la.qbias = w.qbias; la.ldq = ldq;
-        la.Ocat = folded + fm.layer[l].Ocat; la.obias0 = w.obias0; la.obias1 = w.obias1;
-        la.w_ih = P->gru_w_ih; la.w_hh = P->gru_w_hh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
-        la.cw0 = P->context_w0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
+        la.Mcat = folded + fm.layer[l].pMcat; la.qbias = w.qbias; la.ldq = ldq;
+        la.Ocat = folded + fm.layer[l].pOcat; la.obias0 = w.obias0; la.obias1 = w.obias1;
+        la.w_ih = folded + fm.pWih; la.w_hh = folded + fm.pWhh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
+        la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
+        la.heavy_slot = w.heavy_slot; la.zheavy = w.Z;
+        // qt of the heavy rows: gathered-row GEMM into the compact buffer w.Qt, then one block per heavy row
+        {
+            eh_gemm_desc d = {};
+            d.A = hcur; d.lda = 64; d.K1 = 64; d.arow_index = w.heavy_nodes; d.W = folded + fm.layer[l].pMcat; d.w_packed = 1;
+            d.K = 64; d.N = h * 64; d.Y = w.Qt; d.ldy = h * 64; d.act = 0; d.M = Nn; d.m_dev = w.heavy_count;
+            d.prof_id = EH_K_GEMM_QT;
+            int rc = eh_launch_gemm(d, s);
+            if (rc != EDGEHIP_OK) return rc;
+            hipLaunchKernelGGL(k_heavy_qbias, dim3(1024), dim3(256), 0, s, *L, h * 64, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Qt);
+        }
+        const int hb = Nn < 4096 ? Nn : 4096;
+        switch (h) {
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
+        }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
             case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(256), 0, s, *L, la)); break;
@@ -907,17 +1172,17 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     EH_PROF(EH_K_GATHER, s, hipLaunchKernelGGL(k_gather_active, dim3(tile_blocks), dim3(256), 0, s, *L, *P, act_nodes, kptr, hcur, w.ctx, deg,
                        d0, w.Xact));
     eh_gemm_desc g0 = {};
-    g0.A = w.Xact; g0.lda = 256; g0.K1 = 256; g0.W = P->node_out_w0; g0.K = 256; g0.N = 128; g0.bias = P->node_out_b0;
+    g0.A = w.Xact; g0.lda = 256; g0.K1 = 256; g0.W = folded + fm.pNo0; g0.w_packed = 1; g0.K = 256; g0.N = 128; g0.bias = P->node_out_b0;
     g0.Y = w.U1; g0.ldy = 128; g0.act = 1; g0.M = Nn; g0.m_dev = &counts->k_total;
     g0.prof_id = EH_K_GEMM_TAIL;
     int rc = eh_launch_gemm(g0, s);
     if (rc != EDGEHIP_OK) return rc;
     eh_gemm_desc g1 = g0;
-    g1.A = w.U1; g1.lda = 128; g1.K1 = 128; g1.W = P->node_out_w2; g1.K = 128; g1.bias = P->node_out_b2; g1.Y = w.U2;
+    g1.A = w.U1; g1.lda = 128; g1.K1 = 128; g1.W = folded + fm.pNo2; g1.K = 128; g1.bias = P->node_out_b2; g1.Y = w.U2;
     rc = eh_launch_gemm(g1, s);
     if (rc != EDGEHIP_OK) return rc;
     eh_gemm_desc g2 = g1;
-    g2.A = w.U2; g2.W = folded + fm.W4f; g2.bias = folded + fm.b4f; g2.Y = node_repr; g2.act = 0;
+    g2.A = w.U2; g2.W = folded + fm.pW4f; g2.bias = folded + fm.b4f; g2.Y = node_repr; g2.act = 0;
     rc = eh_launch_gemm(g2, s);
     if (rc != EDGEHIP_OK) return rc;
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
@@ -997,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e.v[i][c] = eh_silu(fa.v[i][c] + fb.v[i][c] + fc.v[i][c]);
+                    for (int c = 0; c < 4; ++c) e.v[i][c] = eh_silu_fast(fa.v[i][c] + fb.v[i][c] + fc.v[i][c]);
                 eh_frag w;
                 eh_load_frag(w, a.fw2 + (size_t)r * 128 + ko);        eh_mma64(acc0, e, w);
                 eh_load_frag(w, a.fw2 + (size_t)(32 + r) * 128 + ko); eh_mma64(acc1, e, w);
@@ -1006,8 +1271,8 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 int rr = eh_crow(i, lane);
-                hid[wave][rr][r] = eh_silu(acc0[i] + b20);
-                hid[wave][rr][32 + r] = eh_silu(acc1[i] + b21);
+                hid[wave][rr][r] = eh_silu_fast(acc0[i] + b20);
+                hid[wave][rr][32 + r] = eh_silu_fast(acc1[i] + b21);
             }
         }
         __syncthreads();

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libedgehip.so')
+LIB_PATH = os.environ.get('EDGEHIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libedgehip.so')
 
 MAX_LAYERS = 8
 TILE_ROWS = 32

@@ -41,6 +41,8 @@ def main():
     for rep in range(a.reps + 3):
         if rep == 3:
             torch.cuda.synchronize()
+            if hasattr(capi.lib, 'edgehip_debug_read'):
+                capi.lib.edgehip_debug_read((C.c_ulonglong * 16)(), 1)
             capi.lib.edgehip_prof_enable(1)
         batch.adj.copy_(start)
         model.p_sample(batch, a.t, None, None, capi.Rng(100 + rep))
@@ -58,6 +60,12 @@ def main():
         tot += per_step
         print(f'  {k:14s} {1e3 * ms / cnt:9.1f} us/launch  x{cnt // a.reps:2d}  = {1e3 * per_step:9.1f} us/step')
     print(f'  total {1e3 * tot:.1f} us/step')
+    if hasattr(capi.lib, 'edgehip_debug_read'):
+        buf = (C.c_ulonglong * 16)()
+        capi.lib.edgehip_debug_read(buf, 1)
+        tot_c = sum(buf[:7]) or 1
+        names = ['0 load h', 'A qt', 'B attention', 'C conv mma', 'C reduce', 'D gru', 'E ctx']
+        print('  k_layer phase shares (wave 0 cycles):', ', '.join(f'{n} {100 * buf[i] / tot_c:.1f}%' for i, n in enumerate(names)))
 
 
 if __name__ == '__main__':
