@@ -49,25 +49,35 @@ def make_model(n, edges, device, T=T_STEPS):
 
 def kernel_work(name, Nn, launches_per_pass):
     """Algorithmic flops / bytes of ONE launch of a kernel class at this workload (DESIGN.md 'Kernels').
-    gemm_qt / gemm_out / attention run once per layer with different head counts; their per-launch
-    figure is the average over the 5 layers."""
+    Per-layer kernels run once per layer with different head counts; their per-launch figure is the
+    average over the 5 layers.  Flops are those of the FOLDED formulation the library executes
+    (keys / values never formed), i.e. the lower, honest count - not the reference's 2.6 MFLOP/node."""
     hs = HEADS
-    if name == 'gemm_qt':        # [Nn,64] x [64,64h] : read h, write qt
-        fl = np.mean([2.0 * Nn * 64 * 64 * h for h in hs])
-        by = np.mean([Nn * (256 + 256 * h) for h in hs])
-    elif name == 'gemm_out':     # [Nn,64h+64] x [64h+64,64] : read z and h, write conv
-        fl = np.mean([2.0 * Nn * (64 * h + 64) * 64 for h in hs])
-        by = np.mean([Nn * (256 * h + 256 + 256) for h in hs])
-    elif name == 'gru':          # six 64x64 products per node; read conv, h ; write h'
-        fl, by = 2.0 * Nn * 64 * 64 * 6, Nn * 256 * 3
-    elif name == 'ctx':          # 64 -> 256 ; read h, write per-tile sums
-        fl, by = 2.0 * Nn * 64 * 256, Nn * 256 + (Nn / 32) * 1024
-    elif name == 'attention':    # read qt, bit row, write z (neighbour rows of h are L2-resident re-reads)
-        fl = 0.0
-        by = np.mean([Nn * (512 * h) for h in hs]) + Nn * 160
-    else:
+    if name == 'layer':          # fused layer: q~ = h Mcat, conv = [z|h] Ocat, GRU (6 x 64x64), ctx 64->256
+        fl = np.mean([2.0 * Nn * (64 * 64 * h + (64 * h + 64) * 64 + 6 * 64 * 64 + 64 * 256) for h in hs])
+        # HBM: read h row + bit row (~160 B) , write h' row + per-tile context sums; q~/z stay in LDS,
+        # neighbour rows and weights are L2-resident re-reads
+        by = Nn * (256 + 160 + 256) + (Nn / 32) * 1024
+    else:                        # heavy-row attention etc. are data-dependent: no fixed per-launch figure
         return None
     return fl, by
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run
+    inside this process): profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py from two
+    `rocprofv3 --pmc` runs of this same script; None when the file or the kernel is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    pref = {'layer': 'k_layer'}.get(kernel_class)
+    if pref is None or not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        kk = json.load(fh)['kernels']
+    sel = [v for k, v in kk.items() if k.startswith(pref)]
+    if not sel:
+        return None, None
+    n = sum(v['launches'] for v in sel)
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, 'profiles/r01_pmc_traffic.json'
 
 
 def cpu_baseline(model, n, edges, deg, budget_s=20.0):
@@ -192,6 +202,7 @@ def main():
                 ach = by / dur / 1e9
                 roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBPS, 'traffic': None}
+            roof['traffic'], roof['traffic_source'] = pmc_traffic(dom)
             roof['avg_launch_us'] = kern[dom]['avg_us']
             roof['algorithmic_bytes_per_launch'] = by
             roof['algorithmic_flops_per_launch'] = fl
