@@ -140,7 +140,9 @@ def main():
     n, edges = synth.polblogs_like(0)
     model, deg = make_model(n, edges, device)
     B = a.graphs
-    batch = edgehip.GraphBatch([n] * B, degree=[deg] * B, device=device, gid_base=rank * B)
+    gid_base, count = edgehip.shard.shard_generations(world * B, rank, world)     # weak scaling: B per rank
+    assert count == B
+    batch = edgehip.GraphBatch([n] * B, degree=[deg] * B, device=device, gid_base=gid_base)
 
     def one_pass(i):
         return model.sample_batch(batch, seed=1000 + i)
@@ -158,10 +160,7 @@ def main():
         out = one_pass(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = edgehip.shard.max_over_ranks(elapsed, device)
     edges_out = int(out._slice_dict['edge_index'][-1].item())
     value = world * B * a.steps / elapsed
 

@@ -6,3 +6,4 @@ from .batch import GraphBatch  # noqa: F401
 from .model import (BinomialDiffusionActive, TGNN_degree_guided, add_model_args, elbo_bpd, get_model,  # noqa: F401
                     get_model_id)
 from .sampler import EmpiricalEmptyGraphGenerator  # noqa: F401
+from . import shard  # noqa: F401

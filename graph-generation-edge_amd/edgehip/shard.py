@@ -1,0 +1,50 @@
+"""shard.py - how the path spreads over GPUs: one process per GPU, graphs are independent.
+
+Sampling: rank r of G takes a contiguous block of the `num_generation` graphs and keys its
+RNG streams with the GLOBAL graph id (`gid_base`), so the union of the shards is the same set of graphs a
+single process would have sampled.  There is no collective on the data path; the only communication is
+the timing reduction of the benchmark (MAX over ranks) and an optional gather of per-graph edge counts.
+"""
+import torch
+
+
+def shard_generations(num_generation, rank, world):
+    """(gid_base, count) of rank's block: blocks differ by at most one graph, earlier ranks get the
+    remainder.  Reference: `model.sample(num_generation)` is a single call (experiment.py:67)."""
+    if not (0 <= rank < world):
+        raise ValueError(f'rank {rank} outside world {world}')
+    if num_generation < 0:
+        raise ValueError('num_generation must be >= 0')
+    q, r = divmod(num_generation, world)
+    count = q + (1 if rank < r else 0)
+    base = rank * q + min(rank, r)
+    return base, count
+
+
+def max_over_ranks(value, device='cpu'):
+    """MAX of a python float over the process group (RCCL on GPUs, gloo on CPU); identity if not initialised."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_edge_counts(edges_per_graph, device='cpu'):
+    """All ranks' per-graph edge counts in global graph order (int64 [num_generation]); shards may differ
+    in length by one, so counts are padded to the longest shard for the all_gather."""
+    import torch.distributed as td
+    e = torch.as_tensor(edges_per_graph, dtype=torch.int64, device=device)
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return e
+    world = td.get_world_size()
+    n = torch.tensor([e.numel()], dtype=torch.int64, device=device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    td.all_gather(ns, n)
+    m = int(max(int(x.item()) for x in ns))
+    pad = torch.zeros(m, dtype=torch.int64, device=device)
+    pad[:e.numel()] = e
+    outs = [torch.zeros_like(pad) for _ in range(world)]
+    td.all_gather(outs, pad)
+    return torch.cat([o[:int(k.item())] for o, k in zip(outs, ns)])

@@ -1,0 +1,72 @@
+"""N>1 path on CPU: two gloo processes run the sharding / reduction logic bench.py and the sampler use
+(graphs are independent, rank r takes a contiguous block, RNG keyed by global graph id)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'graph-generation-edge_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    from edgehip import shard
+    import helpers as H
+    base, count = shard.shard_generations(total, rank, world)
+    # the uniforms rank r draws for its local graph j are those of global graph base + j
+    u_local = H.rng_node_uniforms(7, [5] * count, 3, gid_base=base)
+    u_global = H.rng_node_uniforms(7, [5] * total, 3, gid_base=0)
+    same = bool(np.array_equal(u_local, u_global[base * 5:(base + count) * 5]))
+    mx = shard.max_over_ranks(1.0 + rank)
+    counts = shard.gather_edge_counts([100 * (base + j) for j in range(count)])
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, base, count, same, mx, counts.tolist()))
+
+
+@pytest.mark.parametrize('total', [7, 8])
+def test_two_rank_sharding(total):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    covered = []
+    for rank, base, count, same, mx, counts in got:
+        assert same, 'shard RNG streams differ from the single-process streams'
+        assert mx == 2.0
+        assert counts == [100 * g for g in range(total)]
+        covered += list(range(base, base + count))
+    assert covered == list(range(total))
+    assert abs(got[0][2] - got[1][2]) <= 1
+
+
+def test_shard_edges():
+    from edgehip import shard
+    assert shard.shard_generations(0, 0, 4) == (0, 0)
+    assert [shard.shard_generations(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    with pytest.raises(ValueError):
+        shard.shard_generations(4, 4, 4)
+    assert shard.max_over_ranks(3.5) == 3.5
