@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 enum {
     EH_K_DEGREE = 0, EH_K_SELECT, EH_K_OFFSETS, EH_K_TIME_EMBED, EH_K_NODE_IN, EH_K_GRAPH_UPDATE, EH_K_GEMM_QT,
-    EH_K_ATTN, EH_K_GEMM_OUT, EH_K_GRU, EH_K_CTX, EH_K_GATHER, EH_K_GEMM_TAIL, EH_K_PAIR, EH_K_QSAMPLE, EH_K_LAYER, EH_K_MISC,
+    EH_K_ATTN, EH_K_GEMM_OUT, EH_K_GRU, EH_K_CTX, EH_K_GATHER, EH_K_GEMM_TAIL, EH_K_PAIR, EH_K_QSAMPLE, EH_K_LAYER, EH_K_MISC, EH_K_TRAIN,
     EH_K_COUNT
 };
 bool eh_prof_on();

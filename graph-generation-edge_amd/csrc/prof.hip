@@ -19,7 +19,7 @@ hipEvent_t take() {
 }
 const char* kNames[EH_K_COUNT] = {"degree", "select", "offsets", "time_embed", "node_in", "graph_update", "gemm_qt",
                                   "attention", "gemm_out", "gru", "ctx", "gather_active", "gemm_tail", "pair",
-                                  "q_sample", "layer", "misc"};
+                                  "q_sample", "layer", "misc", "train_ops"};
 }  // namespace
 
 bool eh_prof_on() { return g_on; }

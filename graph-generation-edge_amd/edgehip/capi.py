@@ -75,6 +75,26 @@ EXPORTS = {
     'edgehip_sample_step': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp,
                             C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
     'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],
+    # training ops (csrc/train.hip)
+    'edgehip_train_embed_fwd': [C.POINTER(Layout), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],
+    'edgehip_train_embed_bwd': [C.POINTER(Layout), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],
+    'edgehip_linear_bwd_input': [vp, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, vp],
+    'edgehip_linear_bwd_weight': [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp],
+    'edgehip_act_fwd': [C.c_int32, vp, C.c_int64, vp, vp],
+    'edgehip_act_bwd': [C.c_int32, vp, vp, C.c_int64, vp, vp],
+    'edgehip_assemble_fwd': [C.POINTER(Layout), vp, vp, vp, vp, C.c_int32, vp, vp],
+    'edgehip_assemble_bwd': [C.POINTER(Layout), vp, C.c_int32, vp, vp, vp, vp, vp],
+    'edgehip_segment_mean_fwd': [C.POINTER(Layout), vp, vp, vp, vp],
+    'edgehip_segment_mean_bwd': [C.POINTER(Layout), vp, vp, vp],
+    'edgehip_attn_fwd': [C.POINTER(Layout), vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp],
+    'edgehip_attn_bwd': [C.POINTER(Layout), vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    'edgehip_gru_gate_fwd': [vp, vp, vp, C.c_int64, vp, vp],
+    'edgehip_gru_gate_bwd': [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp],
+    'edgehip_pair_gather_add_fwd': [vp, C.c_int32, vp, vp, C.c_int64, vp, vp],
+    'edgehip_pair_gather_add_bwd': [vp, C.c_int32, vp, vp, C.c_int64, vp, vp],
+    'edgehip_pair_targets': [C.POINTER(Layout), vp, vp, vp, C.c_int64, vp, vp, vp],
+    'edgehip_edge_ce_fwd': [vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp],
+    'edgehip_edge_ce_bwd': [vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp],
 }
 SIZE_EXPORTS = {
     'edgehip_gnn_folded_floats': [C.POINTER(GnnParams)],

@@ -447,12 +447,15 @@ class BinomialDiffusionActive(nn.Module):
             if self.loss_type in ('vb_kl', 'vb_ce_xt', 'vb_ce_xt_kl_st', 'vb_ce_xt_ce_st'):
                 raise NotImplementedError(f"loss_type '{self.loss_type}' is outside the accelerated hot path")
             raise ValueError()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._denoise_fn.parameters()):
+            return self._loss(batch, self.training, t, pt, u_tm1, u_t, want, differentiable=True)
         with torch.no_grad():
             return self._loss(batch, self.training, t, pt, u_tm1, u_t, want)
 
-    def _loss(self, batch, training, t, pt, u_tm1, u_t, want):
+    def _loss(self, batch, training, t, pt, u_tm1, u_t, want, differentiable=False):
         """_train_loss / _eval_loss, diffusion_binomial_active.py:228-264 / 195-226. Returns -vb [B].
-        (Forward only: the backward kernels are not built yet, the result carries no grad.)"""
+        differentiable=False: the fused inference kernels (no grad).  True: the op-by-op training form
+        (edgehip/train.py), whose result back-propagates to the network's parameters."""
         L, dev, B = batch.layout, batch.device, batch.num_graphs
         if t is None:
             t, pt = self._sample_time(B, dev, self.sample_time_method)
@@ -477,26 +480,39 @@ class BinomialDiffusionActive(nn.Module):
         self._set_offsets(batch)
         st['adj_t'], st['adj_tm1'], st['deg_tm1'], st['t_graph'] = adj_t, adj_tm1, deg_tm1, t_graph
         net = self._denoise_fn
-        P, folded = net.c_params()
-        ws = _workspace(batch, P)
-        node_repr = torch.empty((batch.num_nodes + 32, 128), dtype=torch.float32, device=dev)
-        capi.check(capi.lib.edgehip_gnn_forward(
-            byref(L), byref(P), folded.data_ptr(), adj_t.data_ptr(), st['deg_t'].data_ptr(),
-            batch.degree_i32.data_ptr(), t_graph.data_ptr(), 0, st['flags'].data_ptr(), st['act_nodes'].data_ptr(),
-            st['kptr'].data_ptr(), st['counts'].data_ptr(), node_repr.data_ptr(), None, ws.data_ptr(), ws.numel(), s),
-            'gnn_forward')
-        A = int(st['aptr'][-1].item())
-        ntile = int(st['tptr'][-1].item())
-        partial = torch.zeros(max(ntile, 1), dtype=torch.float32, device=dev)
-        kl = torch.empty(B, dtype=torch.float32, device=dev)
-        logits = torch.empty((A, 2), dtype=torch.float32, device=dev) if want is not None else None
-        capi.check(capi.lib.edgehip_edge_ce_loss(
-            byref(L), byref(P), folded.data_ptr(), node_repr.data_ptr(), st['act_nodes'].data_ptr(),
-            st['kptr'].data_ptr(), st['aptr'].data_ptr(), st['tptr'].data_ptr(), st['counts'].data_ptr(),
-            adj_tm1.data_ptr(), partial.data_ptr(), ntile, kl.data_ptr(), capi.ptr(logits) if A and logits is not None else None,
-            A, s), 'edge_ce_loss')
+        if differentiable:
+            from . import train
+            if net._pos_emb is None or net._pos_emb.device != dev:
+                net._pos_emb = tables.pos_emb_table(net.num_steps, net.dim).to(dev)
+            self.materialize_actives(batch)
+            row, col = batch.active_row, batch.active_col
+            tgt, pair_graph = train.pair_targets(batch, adj_tm1, row, col)
+            ce, logits = train.tgnn_ce_forward(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, row, col, tgt,
+                                               pair_graph)
+            npairs = batch.edges_per_graph.to(dev).float()
+            n_act = (st['aptr'][1:] - st['aptr'][:-1]).float()
+            kl = ce + 6.9078e-29 * (npairs - n_act) + 6.9078e-29 * npairs          # active.py:176-181
+        else:
+            P, folded = net.c_params()
+            ws = _workspace(batch, P)
+            node_repr = torch.empty((batch.num_nodes + 32, 128), dtype=torch.float32, device=dev)
+            capi.check(capi.lib.edgehip_gnn_forward(
+                byref(L), byref(P), folded.data_ptr(), adj_t.data_ptr(), st['deg_t'].data_ptr(),
+                batch.degree_i32.data_ptr(), t_graph.data_ptr(), 0, st['flags'].data_ptr(), st['act_nodes'].data_ptr(),
+                st['kptr'].data_ptr(), st['counts'].data_ptr(), node_repr.data_ptr(), None, ws.data_ptr(), ws.numel(), s),
+                'gnn_forward')
+            A = int(st['aptr'][-1].item())
+            ntile = int(st['tptr'][-1].item())
+            partial = torch.zeros(max(ntile, 1), dtype=torch.float32, device=dev)
+            kl = torch.empty(B, dtype=torch.float32, device=dev)
+            logits = torch.empty((A, 2), dtype=torch.float32, device=dev) if want is not None else None
+            capi.check(capi.lib.edgehip_edge_ce_loss(
+                byref(L), byref(P), folded.data_ptr(), node_repr.data_ptr(), st['act_nodes'].data_ptr(),
+                st['kptr'].data_ptr(), st['aptr'].data_ptr(), st['tptr'].data_ptr(), st['counts'].data_ptr(),
+                adj_tm1.data_ptr(), partial.data_ptr(), ntile, kl.data_ptr(),
+                capi.ptr(logits) if A and logits is not None else None, A, s), 'edge_ce_loss')
         if training:     # active.py:250-254
-            Lt2 = kl.pow(2)
+            Lt2 = kl.detach().pow(2)
             prev = self.Lt_history.gather(dim=0, index=t)
             self.Lt_history.scatter_(dim=0, index=t, src=(0.1 * Lt2 + 0.9 * prev))
             self.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(Lt2))
@@ -504,7 +520,7 @@ class BinomialDiffusionActive(nn.Module):
         vb = kl / pt + prior
         batch.num_entries = batch.num_pairs            # active.py:192-193
         if want is not None:
-            want.update(kl=kl, kl_prior=prior, logits=logits, t=t, pt=pt)
+            want.update(kl=kl.detach(), kl_prior=prior, logits=logits, t=t, pt=pt)
         return -vb
 
 

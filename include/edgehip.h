@@ -239,6 +239,86 @@ int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_params* P, co
 int edgehip_linear_fwd(const float* X, int64_t M, int32_t K, const float* W, const float* bias, int32_t N,
                        int32_t act, float* Y, void* stream);
 
+/* ================================================================================================
+ * Training ops: forward kernels that keep what the backward needs + their backward twins
+ * (SURVEY.md 8b "ops ... _bwd twins in training").  edgehip/train.py composes them, one
+ * torch.autograd.Function per op; nothing is folded here, so gradients land on the reference's own
+ * parameters.  All buffers fp32 row-major unless noted; "accumulates" = float atomics into a buffer the
+ * caller zero-filled.
+ * ================================================================================================ */
+
+/* replaces: embedding_t / embedding_0 / embedding_sel + cat, layers/layers.py:326-336
+ * X0[Nn,192] = [ w_t*min(deg,dmax+1)/dmax + b_t | w_0*d0/dmax + b_0 | emb_sel[flag] ].
+ * bwd accumulates dwt,dbt,dw0,db0 [64] and dwsel [2,64]. */
+int edgehip_train_embed_fwd(const edgehip_layout* L, const int32_t* deg, const int32_t* d0, const uint8_t* flags,
+                            int32_t max_degree, const float* wt, const float* bt, const float* w0, const float* b0,
+                            const float* wsel, float* X0, void* stream);
+int edgehip_train_embed_bwd(const edgehip_layout* L, const int32_t* deg, const int32_t* d0, const uint8_t* flags,
+                            int32_t max_degree, const float* dX0, float* dwt, float* dbt, float* dw0, float* db0,
+                            float* dwsel, void* stream);
+
+/* replaces: autograd of torch.nn.Linear (every Linear of layers/layers.py:257-313)
+ * bwd_input:  dX[M,K] = dY[M,N] W[N,K]   (N % 64 == 0, K % 32 == 0; WT_scratch: K*N floats)
+ * bwd_weight: dW[N,K] += dY^T X, db[N] += column sums of dY (db may be NULL); accumulates. */
+int edgehip_linear_bwd_input(const float* dY, int64_t M, int32_t N, const float* W, int32_t K, float* WT_scratch,
+                             float* dX, void* stream);
+int edgehip_linear_bwd_weight(const float* dY, const float* X, int64_t M, int32_t N, int32_t K, float* dW, float* db,
+                              void* stream);
+
+/* replaces: nn.SiLU (kind 1) and Mish (kind 2, layers/layers.py:40-42) and their autograd */
+int edgehip_act_fwd(int32_t kind, const float* x, int64_t n, float* y, void* stream);
+int edgehip_act_bwd(int32_t kind, const float* x, const float* dy, int64_t n, float* dx, void* stream);
+
+/* replaces: `nodes + contexts`, torch.cat with the repeat_interleave'd per-graph rows,
+ *           layers/layers.py:345,350-353,366,369-371,377
+ * out[Nn,64+Kt] = [ h[i] + ctx[g(i)] | tail_graph[g(i)] (Kt = 64) or tail_rows[i] (any Kt) ]; ctx may be NULL.
+ * bwd: dh[Nn,64]; dctx[B,64], dtail_graph[B,64] per-graph column sums; dtail_rows[Nn,Kt] (any may be NULL). */
+int edgehip_assemble_fwd(const edgehip_layout* L, const float* h, const float* ctx, const float* tail_graph,
+                         const float* tail_rows, int32_t Kt, float* out, void* stream);
+int edgehip_assemble_bwd(const edgehip_layout* L, const float* dout, int32_t Kt, float* dh, float* dctx,
+                         float* dtail_graph, float* dtail_rows, void* stream);
+
+/* replaces: torch_scatter.scatter(reduce='mean') over `batch`, layers/layers.py:342,367
+ * out[B,64] = add[B,64] (or 0) + per-graph mean of x[Nn,64];  bwd: dx[i] = dout[g(i)] / n_g. */
+int edgehip_segment_mean_fwd(const edgehip_layout* L, const float* x, const float* add, float* out, void* stream);
+int edgehip_segment_mean_bwd(const edgehip_layout* L, const float* dout, float* dx, void* stream);
+
+/* replaces: pyg.nn.TransformerConv message passing + softmax + mean over heads + root skip
+ *           (call site layers/layers.py:354) over the bit-matrix neighbourhoods.
+ * q,k,v [Nn,heads*64]; skip,out [Nn,64]; saved for backward: O [Nn,heads*64] per-head outputs,
+ * lse [Nn,heads].  bwd: Dbuf [Nn,heads] scratch; dq,dk,dv [Nn,heads*64] (dskip = dout). */
+int edgehip_attn_fwd(const edgehip_layout* L, const uint32_t* adj, int32_t heads, const float* q, const float* k,
+                     const float* v, const float* skip, float* out, float* O, float* lse, void* stream);
+int edgehip_attn_bwd(const edgehip_layout* L, const uint32_t* adj, int32_t heads, const float* q, const float* k,
+                     const float* v, const float* O, const float* lse, const float* dout, float* Dbuf, float* dq,
+                     float* dk, float* dv, void* stream);
+
+/* replaces: the gate arithmetic of torch.nn.GRU(64,64), one step, layers/layers.py:360
+ * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh ([Nn,192], gates r,z,n) -> h' [Nn,64]. */
+int edgehip_gru_gate_fwd(const float* gi, const float* gh, const float* h, int64_t Nn, float* hout, void* stream);
+int edgehip_gru_gate_bwd(const float* gi, const float* gh, const float* h, const float* dhout, int64_t Nn, float* dgi,
+                         float* dgh, float* dh, void* stream);
+
+/* replaces: nodes[row] + nodes[col] on the active pairs, layers/layers.py:380 (bwd accumulates into dz) */
+int edgehip_pair_gather_add_fwd(const float* z, int32_t width, const int64_t* row, const int64_t* col, int64_t A, float* e,
+                                void* stream);
+int edgehip_pair_gather_add_bwd(const float* de, int32_t width, const int64_t* row, const int64_t* col, int64_t A,
+                                float* dz, void* stream);
+
+/* replaces: log_full_edge_attr_tmin1[active_edge_indices] and batch[row], diffusion_binomial_active.py:165-170
+ * tgt[A] = bit of pair (row,col) in x_{t-1}; pair_graph[A] = graph of the pair. */
+int edgehip_pair_targets(const edgehip_layout* L, const uint32_t* adj_tm1, const int64_t* row, const int64_t* col, int64_t A,
+                         uint8_t* tgt, int32_t* pair_graph, void* stream);
+
+/* replaces: final_out[4] (64 -> 2) layers/layers.py:381 + log_softmax + cross-entropy + per-graph sum,
+ *           _compute_MC_KL_joint diffusion_binomial_active.py:157-175
+ * fwd: logits[A,2]; ce_graph[B] accumulates sum_k CE_k.  bwd: gkl[B] = dLoss/dce_graph;
+ * de2[A,64]; dW4[2,64], db4[2] accumulate. */
+int edgehip_edge_ce_fwd(const float* e2, const float* W4, const float* b4, const uint8_t* tgt, const int32_t* pair_graph,
+                        int64_t A, float* logits, float* ce_graph, void* stream);
+int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float* b4, const uint8_t* tgt, const int32_t* pair_graph,
+                        const float* gkl, int64_t A, float* de2, float* dW4, float* db4, void* stream);
+
 /* ---- measurement hooks (no counterpart in the reference; used by bench.py's roofline leg) -------
  * When enabled, every kernel launch of the path is bracketed by HIP events on its launch stream.
  * collect() synchronises on those events and returns, per kernel class, the summed device time (ms)

@@ -88,7 +88,7 @@ def set_state_from_pair_indices(batch, idx):
 
 
 def rel_err(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     if b.numel() == 0:
         return 0.0
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))

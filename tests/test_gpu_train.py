@@ -1,0 +1,262 @@
+"""GPU: the training ops (csrc/train.hip) against plain PyTorch fp32/fp64 references of the same op, and the
+gradient of the whole loss against the oracle's autograd (torch CPU restatement of the reference).
+
+Tolerance: gradients are sums of fp32 products in a different order than torch's, so they are compared
+as max|gpu - ref| / max|ref| per tensor with GRAD_TOL = 2e-4 (the forward bound is 1e-4)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+import helpers as H
+from oracle import edge_oracle as orc
+
+pytestmark = pytest.mark.gpu
+byref = C.byref
+GRAD_TOL = 2e-4
+
+
+def _rand_graphs(seed, sizes, p=0.15):
+    rng = np.random.default_rng(seed)
+    gs = []
+    for n in sizes:
+        iu = np.triu_indices(n, 1)
+        keep = rng.random(len(iu[0])) < p
+        gs.append(dict(n=n, edges=np.stack([iu[0][keep], iu[1][keep]], 1).astype(np.int64)))
+    return gs
+
+
+def _dense_adj(graphs):
+    Nn = sum(g['n'] for g in graphs)
+    A = torch.zeros(Nn, Nn, dtype=torch.bool)
+    o = 0
+    for g in graphs:
+        e = torch.as_tensor(g['edges'])
+        if len(e):
+            A[o + e[:, 0], o + e[:, 1]] = True
+            A[o + e[:, 1], o + e[:, 0]] = True
+        o += g['n']
+    return A
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 64, 64), (37, 128, 512), (1222, 192, 64), (4888, 64, 192), (300, 256, 128), (5, 512, 64)])
+def test_linear_backward_vs_torch(M, K, N):
+    from edgehip import train
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).cuda().requires_grad_()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().requires_grad_()
+    b = torch.randn(N, generator=g).cuda().requires_grad_()
+    dy = torch.randn(M, N, generator=g).cuda()
+    y = train._Linear.apply(x, w, b)
+    y.backward(dy)
+    xr, wr, br = (t.detach().double().cpu().requires_grad_() for t in (x, w, b))
+    F.linear(xr, wr, br).backward(dy.double().cpu())
+    assert H.rel_err(x.grad, xr.grad) < 2e-6
+    assert H.rel_err(w.grad, wr.grad) < 2e-6
+    assert H.rel_err(b.grad, br.grad) < 2e-6
+
+
+@pytest.mark.parametrize('kind', [1, 2])
+def test_activation_vs_torch(kind):
+    from edgehip import train
+    x = (torch.randn(1000, 64, generator=torch.Generator().manual_seed(kind)) * 4).cuda().requires_grad_()
+    dy = torch.randn(1000, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    y = train.act(x, kind)
+    y.backward(dy)
+    xr = x.detach().double().cpu().requires_grad_()
+    yr = F.silu(xr) if kind == 1 else xr * torch.tanh(F.softplus(xr))
+    yr.backward(dy.double().cpu())
+    assert H.rel_err(y, yr) < 1e-6
+    assert H.rel_err(x.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('heads', [1, 2, 4, 8])
+def test_attention_fwd_bwd_vs_dense_torch(heads):
+    """TransformerConv semantics on a ragged batch with isolated nodes."""
+    from edgehip import train
+    graphs = _rand_graphs(heads, [1, 33, 70, 5], p=0.12)
+    graphs[2]['edges'] = graphs[2]['edges'][graphs[2]['edges'].min(1) > 3]        # nodes 0..3 isolated
+    b = H.graph_batch(graphs)
+    Nn = b.num_nodes
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(Nn, heads * 64, generator=g) for _ in range(3))
+    skip, dout = torch.randn(Nn, 64, generator=g), torch.randn(Nn, 64, generator=g)
+    qd, kd, vd, sd = (t.cuda().requires_grad_() for t in (q, k, v, skip))
+    out = train._Attention.apply(qd, kd, vd, sd, b.layout, b.adj, heads)
+    out.backward(dout.cuda())
+    A = _dense_adj(graphs)
+    qr, kr, vr, sr = (t.double().requires_grad_() for t in (q, k, v, skip))
+    s = torch.einsum('ihc,jhc->hij', qr.view(Nn, heads, 64), kr.view(Nn, heads, 64)) / 8.0
+    s = s.masked_fill(~A[None], float('-inf'))
+    a = torch.softmax(s, dim=-1)
+    a = torch.where(A[None].expand_as(a), a, torch.zeros_like(a))                 # rows with no neighbour -> 0
+    ref = torch.einsum('hij,jhc->ihc', a, vr.view(Nn, heads, 64)).mean(1) + sr
+    ref.backward(dout.double())
+    assert H.rel_err(out, ref) < 2e-6
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad), (sd.grad, sr.grad)):
+        assert H.rel_err(got, want) < 5e-6
+
+
+def test_gru_gate_vs_torch():
+    from edgehip import train
+    g = torch.Generator().manual_seed(3)
+    gi, gh, h, dh = torch.randn(777, 192, generator=g), torch.randn(777, 192, generator=g), torch.randn(777, 64, generator=g), \
+        torch.randn(777, 64, generator=g)
+    a, b_, c = (t.cuda().requires_grad_() for t in (gi, gh, h))
+    out = train._GruGate.apply(a, b_, c)
+    out.backward(dh.cuda())
+    ar, br, cr = (t.double().requires_grad_() for t in (gi, gh, h))
+    i_r, i_z, i_n = ar.chunk(3, 1)
+    h_r, h_z, h_n = br.chunk(3, 1)
+    r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    ref = (1 - z) * n + z * cr
+    ref.backward(dh.double())
+    assert H.rel_err(out, ref) < 1e-6
+    for got, want in ((a.grad, ar.grad), (b_.grad, br.grad), (c.grad, cr.grad)):
+        assert H.rel_err(got, want) < 2e-6
+
+
+def test_assemble_segment_pair_embed_vs_torch():
+    from edgehip import train
+    graphs = _rand_graphs(2, [40, 1, 77])
+    b = H.graph_batch(graphs)
+    L, Nn, B = b.layout, b.num_nodes, b.num_graphs
+    bi = b.batch.long().cpu()
+    g = torch.Generator().manual_seed(8)
+    h, tr = torch.randn(Nn, 64, generator=g), torch.randn(Nn, 192, generator=g)
+    cx, tg = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    # assemble, both tail kinds
+    for tail in ('graph', 'rows'):
+        hd, cd = h.cuda().requires_grad_(), cx.cuda().requires_grad_()
+        td = (tg if tail == 'graph' else tr).cuda().requires_grad_()
+        out = train._Assemble.apply(hd, cd, td if tail == 'graph' else None, td if tail == 'rows' else None, L)
+        hr, cr = h.double().requires_grad_(), cx.double().requires_grad_()
+        t_r = (tg if tail == 'graph' else tr).double().requires_grad_()
+        ref = torch.cat([hr + cr[bi], t_r[bi] if tail == 'graph' else t_r], 1)
+        dy = torch.randn(ref.shape, generator=g)
+        out.backward(dy.cuda())
+        ref.backward(dy.double())
+        assert H.rel_err(out, ref) < 1e-6
+        for got, want in ((hd.grad, hr.grad), (cd.grad, cr.grad), (td.grad, t_r.grad)):
+            assert H.rel_err(got, want) < 2e-6
+    # segment mean with addend
+    xd, ad = h.cuda().requires_grad_(), cx.cuda().requires_grad_()
+    out = train._SegmentMean.apply(xd, ad, L)
+    xr, ar = h.double().requires_grad_(), cx.double().requires_grad_()
+    cnt = torch.bincount(bi, minlength=B).double()
+    ref = ar + torch.zeros(B, 64, dtype=torch.float64).index_add(0, bi, xr) / cnt[:, None]
+    dy = torch.randn(B, 64, generator=g)
+    out.backward(dy.cuda())
+    ref.backward(dy.double())
+    assert H.rel_err(out, ref) < 1e-6 and H.rel_err(xd.grad, xr.grad) < 1e-6 and H.rel_err(ad.grad, ar.grad) < 1e-6
+    # pair gather-add
+    A = 500
+    row = torch.randint(0, Nn, (A,), generator=g)
+    col = torch.randint(0, Nn, (A,), generator=g)
+    z = torch.randn(Nn, 128, generator=g)
+    zd = z.cuda().requires_grad_()
+    e = train._PairGatherAdd.apply(zd, row.cuda(), col.cuda())
+    zr = z.double().requires_grad_()
+    er = zr[row] + zr[col]
+    dy = torch.randn(A, 128, generator=g)
+    e.backward(dy.cuda())
+    er.backward(dy.double())
+    assert H.rel_err(e, er) < 1e-6 and H.rel_err(zd.grad, zr.grad) < 2e-6
+    # embeddings
+    deg = torch.randint(0, 12, (Nn,), generator=g, dtype=torch.int32)
+    flags = torch.randint(0, 2, (Nn,), generator=g, dtype=torch.uint8)
+    dmax = 9
+    ws = [torch.randn(64, 1, generator=g), torch.randn(64, generator=g), torch.randn(64, 1, generator=g),
+          torch.randn(64, generator=g), torch.randn(2, 64, generator=g)]
+    wd = [w.cuda().requires_grad_() for w in ws]
+    X0 = train._Embed.apply(*wd, L, deg.cuda(), b.degree_i32, flags.cuda(), dmax)
+    wr = [w.double().requires_grad_() for w in ws]
+    st = (deg.clamp(max=dmax + 1).double() / dmax)[:, None]
+    s0 = (b.degree_i32[:Nn].cpu().double() / dmax)[:, None]
+    ref = torch.cat([F.linear(st, wr[0], wr[1]), F.linear(s0, wr[2], wr[3]), F.embedding(flags.long(), wr[4])], 1)
+    dy = torch.randn(Nn, 192, generator=g)
+    X0.backward(dy.cuda())
+    ref.backward(dy.double())
+    assert H.rel_err(X0, ref) < 1e-6
+    for got, want in zip(wd, wr):
+        assert H.rel_err(got.grad, want.grad) < 2e-6
+
+
+def test_edge_ce_vs_torch():
+    from edgehip import train
+    g = torch.Generator().manual_seed(21)
+    A, B = 3001, 3
+    e2, W4, b4 = torch.randn(A, 64, generator=g), torch.randn(2, 64, generator=g) / 8, torch.randn(2, generator=g)
+    tgt = torch.randint(0, 2, (A,), generator=g, dtype=torch.uint8)
+    pg = torch.sort(torch.randint(0, B, (A,), generator=g, dtype=torch.int32))[0]
+    gk = torch.randn(B, generator=g)
+    ed, wd, bd = (t.cuda().requires_grad_() for t in (e2, W4, b4))
+    ce, logits = train._EdgeCE.apply(ed, wd, bd, tgt.cuda(), pg.cuda(), B)
+    ce.backward(gk.cuda())
+    er, wr, br = (t.double().requires_grad_() for t in (e2, W4, b4))
+    lr = F.linear(er, wr, br)
+    cer = torch.zeros(B, dtype=torch.float64).index_add(0, pg.long(), F.cross_entropy(lr, tgt.long(), reduction='none'))
+    cer.backward(gk.double())
+    assert H.rel_err(logits, lr) < 1e-6 and H.rel_err(ce, cer) < 1e-5
+    for got, want in ((ed.grad, er.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert H.rel_err(got, want) < 5e-6
+
+
+@pytest.mark.parametrize('name,case', [('loss_toy', 'toy'), ('loss_toy_mid', 'toy'), ('loss_ragged', 'ragged'),
+                                       ('loss_polblogs1', 'polblogs1')])
+def test_loss_gradient_vs_oracle_autograd(name, case):
+    """elbo_bpd(model, batch).backward() against torch autograd through the oracle on the same t, pt and
+    uniforms (the golden fixture pins the forward values of this very configuration)."""
+    import edgehip
+    g = H.golden(name + '.npz')
+    builder, T, wseed, useed = cases.CASES[case]
+    graphs = builder()
+    rng = np.random.default_rng(useed + 1)
+    Nn = sum(x['n'] for x in graphs)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    us = [cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2), cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)]
+    t, pt = torch.from_numpy(g['t']), torch.from_numpy(g['pt'])
+    params = orc.random_tgnn_params(wseed)
+    # oracle
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    o = orc.EdgeOracle(po, T, int(g['max_degree']))
+    ob = orc.make_batch(graphs, degree_dtype=torch.int64)
+    ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+    ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+    nv_ref = o.loss(ob, t, pt, orc.UniformTape(us), training=True)
+    orc.elbo_bpd(nv_ref, ob.num_entries).backward()
+    # product
+    model = H.build_model(params, T, int(g['max_degree']))
+    model.train()
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    want = {}
+    nv = model.log_prob(b, t, pt, us[1].cuda(), us[3].cuda(), want)
+    assert nv.requires_grad
+    np.testing.assert_allclose(nv.detach().cpu().numpy(), g['neg_vb'], rtol=1e-4, atol=1e-12)
+    if len(g['logits']):
+        assert H.rel_err(want['logits'], g['logits']) < 1e-4
+    bpd = -nv.sum() / (np.log(2) * b.num_entries)
+    bpd.backward()
+    named = dict(model._denoise_fn.named_parameters())
+    checked = 0
+    gmax = max(float(r.grad.abs().max()) for r in po.values() if r.grad is not None)
+    for k, ref in po.items():
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
+            continue
+        assert named[k].grad is not None, k
+        # gradients that are zero in exact arithmetic (the key bias: softmax is shift-invariant) are pure
+        # rounding noise on both sides; measure those against the global gradient scale
+        scale = max(float(ref.grad.abs().max()), 1e-6 * gmax)
+        err = float((named[k].grad.detach().cpu().double() - ref.grad.double()).abs().max()) / scale
+        assert err < GRAD_TOL, (k, err)
+        checked += 1
+    assert checked >= (80 if len(g['logits']) else 0)
+    # the same loss through the fused inference kernels
+    with torch.no_grad():
+        nv2 = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
+    np.testing.assert_allclose(nv2.cpu().numpy(), nv.detach().cpu().numpy(), rtol=1e-4, atol=1e-12)
