@@ -119,6 +119,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--graphs', type=int, default=64, help='graphs sampled per GPU per step (num_generation)')
+    ap.add_argument('--train-steps', type=int, default=10, help='secondary metric: timed training steps (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -207,6 +208,29 @@ def main():
             roof['algorithmic_flops_per_launch'] = fl
         res['roofline'] = roof
         res['kernels'] = kern
+    if a.train_steps > 0:
+        # secondary metric: training steps/sec = elbo_bpd fwd + bwd + clip + Adam on the
+        # reference's polblogs batch (4 copies of the graph with independent t, README.md:70), data-parallel
+        # over the ranks (one flat-bucket gradient all-reduce per step)
+        TB = 4
+        tb = edgehip.GraphBatch([n] * TB, degree=[deg] * TB, edges=[edges] * TB, device=device,
+                                gid_base=rank * TB, degree_dtype=np.int64)
+        tmodel, _ = make_model(n, edges, device)       # a fresh copy: the sampled model stays untouched
+        tmodel.rng_seed = 1234 + rank
+        opt = edgehip.make_optimizer(tmodel)
+        tstate = {}
+        torch.manual_seed(1 + rank)
+        for _ in range(2):
+            edgehip.train_step(tmodel, tb, opt, clip_value=1.0, state=tstate)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.train_steps):
+            bpd = edgehip.train_step(tmodel, tb, opt, clip_value=1.0, state=tstate)
+        barrier()
+        tel = edgehip.shard.max_over_ranks(time.perf_counter() - t0, device)
+        res['train'] = {'metric': 'training steps/sec, polblogs batch 4 per GPU (fwd + bwd + clip + Adam)',
+                        'value': a.train_steps / tel, 'unit': 'steps/s', 'ms_per_step': 1e3 * tel / a.train_steps,
+                        'graphs_per_step': TB * world, 'last_bpd': float(bpd)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(model, n, edges, deg)
     if rank == 0:

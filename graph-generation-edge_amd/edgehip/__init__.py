@@ -7,3 +7,4 @@ from .model import (BinomialDiffusionActive, TGNN_degree_guided, add_model_args,
                     get_model_id)
 from .sampler import EmpiricalEmptyGraphGenerator  # noqa: F401
 from . import shard  # noqa: F401
+from .trainer import make_optimizer, train_step  # noqa: F401

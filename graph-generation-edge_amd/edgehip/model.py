@@ -511,11 +511,13 @@ class BinomialDiffusionActive(nn.Module):
                 st['kptr'].data_ptr(), st['aptr'].data_ptr(), st['tptr'].data_ptr(), st['counts'].data_ptr(),
                 adj_tm1.data_ptr(), partial.data_ptr(), ntile, kl.data_ptr(),
                 capi.ptr(logits) if A and logits is not None else None, A, s), 'edge_ce_loss')
-        if training:     # active.py:250-254
-            Lt2 = kl.detach().pow(2)
-            prev = self.Lt_history.gather(dim=0, index=t)
-            self.Lt_history.scatter_(dim=0, index=t, src=(0.1 * Lt2 + 0.9 * prev))
-            self.Lt_count.scatter_add_(dim=0, index=t, src=torch.ones_like(Lt2))
+        if training:     # active.py:250-254; under data parallelism every replica applies every rank's pairs
+            from . import shard
+            t_all = shard.all_gather_cat(t)
+            Lt2 = shard.all_gather_cat(kl.detach()).pow(2)
+            prev = self.Lt_history.gather(dim=0, index=t_all)
+            self.Lt_history.scatter_(dim=0, index=t_all, src=(0.1 * Lt2 + 0.9 * prev))
+            self.Lt_count.scatter_add_(dim=0, index=t_all, src=torch.ones_like(Lt2))
         prior = self._kl_prior(batch).to(dev)
         vb = kl / pt + prior
         batch.num_entries = batch.num_pairs            # active.py:192-193

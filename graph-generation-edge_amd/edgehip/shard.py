@@ -48,3 +48,65 @@ def gather_edge_counts(edges_per_graph, device='cpu'):
     outs = [torch.zeros_like(pad) for _ in range(world)]
     td.all_gather(outs, pad)
     return torch.cat([o[:int(k.item())] for o, k in zip(outs, ns)])
+
+
+# ---- training (data-parallel replicas) ---------------------------------------------
+def _dist():
+    import torch.distributed as td
+    return td if (td.is_available() and td.is_initialized() and td.get_world_size() > 1) else None
+
+
+def sum_over_ranks(value, device='cpu'):
+    """SUM of a python number over the process group (e.g. the global number of pairs P that
+    normalises elbo_bpd, diffusion/loss.py:10-12)."""
+    td = _dist()
+    if td is None:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t.item())
+
+
+def all_gather_cat(x):
+    """Concatenation of every rank's 1-D tensor in rank order (equal lengths): the (t, kl) pairs every
+    replica must apply to Lt_history / Lt_count so the importance sampler stays identical across ranks
+    (diffusion_binomial_active.py:250-254)."""
+    td = _dist()
+    if td is None:
+        return x
+    outs = [torch.empty_like(x) for _ in range(td.get_world_size())]
+    td.all_gather(outs, x.contiguous())
+    return torch.cat(outs)
+
+
+def allreduce_gradients(params, bucket=None):
+    """ONE flat fp32 bucket (1 123 650 floats = 4.49 MB for the reference network) summed over ranks with a
+    single all-reduce (RCCL over xGMI: latency-bound at this size, so one message, not one per tensor),
+    then scattered back into the .grad tensors.  Parameters without a gradient contribute zeros so the
+    bucket layout is identical on every rank.  Returns the bucket (reusable on the next step)."""
+    td = _dist()
+    ps = [p for p in params if p.requires_grad]
+    if td is None or not ps:
+        return bucket
+    n = sum(p.numel() for p in ps)
+    dev = ps[0].device
+    if bucket is None or bucket.numel() != n or bucket.device != dev:
+        bucket = torch.empty(n, dtype=torch.float32, device=dev)
+    o = 0
+    for p in ps:
+        k = p.numel()
+        if p.grad is None:
+            bucket[o:o + k].zero_()
+        else:
+            bucket[o:o + k].copy_(p.grad.reshape(-1))
+        o += k
+    td.all_reduce(bucket, op=td.ReduceOp.SUM)
+    o = 0
+    for p in ps:
+        k = p.numel()
+        if p.grad is None:
+            p.grad = bucket[o:o + k].view_as(p).clone()
+        else:
+            p.grad.copy_(bucket[o:o + k].view_as(p))
+        o += k
+    return bucket

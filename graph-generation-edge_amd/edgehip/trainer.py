@@ -1,0 +1,35 @@
+"""trainer.py - one optimisation step of the reference's training loop (experiment.py:23-46 of the
+reference: zero_grad -> elbo_bpd -> backward -> clip -> optimizer.step), with the data-parallel
+exchange of SURVEY.md 8e when a process group is up: the loss is normalised by the GLOBAL number of
+pairs, gradients are summed in one flat bucket, and `log_prob` applies every rank's (t, kl) to the
+importance-sampling history so replicas stay identical."""
+import math
+
+import torch
+
+from . import shard
+
+
+def make_optimizer(model, lr=1e-3, momentum=0.9, momentum_sqr=0.999):
+    """The reference default: Adam(lr 1e-3, betas (0.9, 0.999)) (diffusion/optim/multistep.py:27-46)."""
+    return torch.optim.Adam(model.parameters(), lr=lr, betas=(momentum, momentum_sqr))
+
+
+def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=None, **log_prob_kwargs):
+    """Returns the global bits/dim of the step (python float is NOT forced: a 0-d tensor, no host sync)."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    neg_vb = model.log_prob(batch, **log_prob_kwargs)                   # [B], differentiable
+    P = shard.sum_over_ranks(batch.num_entries, batch.device)
+    loss = -neg_vb.sum() / (math.log(2) * P)                            # diffusion/loss.py:10-12
+    loss.backward()
+    params = [p for p in model.parameters()]
+    bucket = shard.allreduce_gradients(params, None if state is None else state.get('bucket'))
+    if state is not None:
+        state['bucket'] = bucket
+    if clip_value:
+        torch.nn.utils.clip_grad_value_(params, clip_value)
+    if clip_norm:
+        torch.nn.utils.clip_grad_norm_(params, clip_norm)
+    optimizer.step()
+    return loss.detach()

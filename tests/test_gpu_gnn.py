@@ -102,9 +102,12 @@ def test_network_forward_vs_oracle_head_configs(heads):
     assert H.rel_err(logits, ref) < TOL
 
 
+@pytest.mark.parametrize('differentiable', [False, True], ids=['fused', 'train_ops'])
 @pytest.mark.parametrize('name,case', [('loss_toy', 'toy'), ('loss_toy_mid', 'toy'), ('loss_ragged', 'ragged'),
                                        ('loss_polblogs1', 'polblogs1')])
-def test_train_loss_vs_reference_golden(name, case):
+def test_train_loss_vs_reference_golden(name, case, differentiable):
+    """_train_loss against the reference's own outputs, through both forms of the forward: the fused
+    inference kernels (torch.no_grad) and the op-by-op differentiable form (grad enabled)."""
     g = H.golden(name + '.npz')
     builder, T, wseed, useed = cases.CASES[case]
     graphs = builder()
@@ -116,7 +119,10 @@ def test_train_loss_vs_reference_golden(name, case):
     model.train()
     b = H.graph_batch(graphs, degree_dtype=np.int64)
     want = {}
-    nv = model.log_prob(b, torch.from_numpy(g['t']), torch.from_numpy(g['pt']), us[1].cuda(), us[3].cuda(), want)
+    with torch.set_grad_enabled(differentiable):
+        nv = model.log_prob(b, torch.from_numpy(g['t']), torch.from_numpy(g['pt']), us[1].cuda(), us[3].cuda(), want)
+    assert nv.requires_grad == differentiable
+    nv = nv.detach()
     st = b._state
     assert np.array_equal(b.pair_bits(st['adj_tm1']).nonzero(as_tuple=True)[0].cpu().numpy(), g['xtm1'])
     assert np.array_equal(b.pair_bits(st['adj_t']).nonzero(as_tuple=True)[0].cpu().numpy(), g['xt'])

@@ -260,3 +260,46 @@ def test_loss_gradient_vs_oracle_autograd(name, case):
     with torch.no_grad():
         nv2 = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
     np.testing.assert_allclose(nv2.cpu().numpy(), nv.detach().cpu().numpy(), rtol=1e-4, atol=1e-12)
+
+
+def test_train_step_matches_oracle_adam_and_learns():
+    """One optimisation step (experiment.py:29-37 of the reference): parameters after Adam equal the ones
+    obtained from the oracle's autograd gradients; a few more steps on the same (t, uniforms) lower the loss."""
+    import edgehip
+    g = H.golden('loss_ragged.npz')
+    builder, T, wseed, useed = cases.CASES['ragged']
+    graphs = builder()
+    rng = np.random.default_rng(useed + 1)
+    Nn = sum(x['n'] for x in graphs)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    us = [cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2), cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)]
+    t, pt = torch.from_numpy(g['t']), torch.from_numpy(g['pt'])
+    params = orc.random_tgnn_params(wseed)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    o = orc.EdgeOracle(po, T, int(g['max_degree']))
+    ob = orc.make_batch(graphs, degree_dtype=torch.int64)
+    ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+    ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+    ref_opt = torch.optim.Adam(list(po.values()), lr=1e-3, betas=(0.9, 0.999))
+    orc.elbo_bpd(o.loss(ob, t, pt, orc.UniformTape(us), training=True), ob.num_entries).backward()
+    torch.nn.utils.clip_grad_value_([p for p in po.values() if p.grad is not None], 1.0)
+    ref_opt.step()
+
+    model = H.build_model(params, T, int(g['max_degree']))
+    opt = edgehip.make_optimizer(model)
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    kw = dict(t=t, pt=pt, u_tm1=us[1].cuda(), u_t=us[3].cuda())
+    losses = [float(edgehip.train_step(model, b, opt, clip_value=1.0, **kw))]
+    # Adam's first step moves every weight by lr * g / (|g| + 1e-8): where |g| ~ 1e-8 the step amplifies the
+    # rounding noise of g, so the bound is 5% of lr element-wise and 0.1% of lr on average
+    for k, v in model._denoise_fn.named_parameters():
+        d = (v.detach().cpu() - po[k].detach()).abs()
+        assert float(d.max()) < 5e-5 and float(d.mean()) < 1e-6, (k, float(d.max()), float(d.mean()))
+    for _ in range(5):
+        losses.append(float(edgehip.train_step(model, b, opt, clip_value=1.0, **kw)))
+    assert losses[-1] < losses[0]
+    # the sampler refolds after the parameters moved (version counters) and still runs
+    model.eval()
+    with torch.no_grad():
+        nv = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
+    assert abs(float(-nv.sum() / (np.log(2) * P)) - losses[-1]) < 0.2 * abs(losses[0] - losses[-1]) + 1e-3

@@ -70,3 +70,41 @@ def test_shard_edges():
     with pytest.raises(ValueError):
         shard.shard_generations(4, 4, 4)
     assert shard.max_over_ranks(3.5) == 3.5
+
+
+def _train_worker(rank, world, port, q):
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    from edgehip import shard
+    g = torch.Generator().manual_seed(100 + rank)
+    params = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.randn(3, 5, generator=g)
+    params[1].grad = torch.randn(7, generator=g) if rank == 0 else None       # missing on one rank: zeros
+    params[2].requires_grad_(False)
+    bucket = shard.allreduce_gradients(params)
+    P = shard.sum_over_ranks(10 + rank)
+    t_all = shard.all_gather_cat(torch.tensor([rank * 2, rank * 2 + 1]))
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, params[0].grad.tolist(), params[1].grad.tolist(), params[2].grad, P, t_all.tolist(), bucket.numel()))
+
+
+def test_two_rank_gradient_bucket_and_history_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in ps), key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    g0 = torch.Generator().manual_seed(100)
+    a0, b0 = torch.randn(3, 5, generator=g0), torch.randn(7, generator=g0)
+    a1 = torch.randn(3, 5, generator=torch.Generator().manual_seed(101))
+    for rank, ga, gb, gc, P, t_all, nb in got:
+        assert torch.allclose(torch.tensor(ga), a0 + a1) and torch.allclose(torch.tensor(gb), b0)
+        assert gc is None and P == 21.0 and t_all == [0, 1, 2, 3] and nb == 22
