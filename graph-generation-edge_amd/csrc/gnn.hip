@@ -637,7 +637,9 @@ __global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __re
 // the bit row split into four word ranges (one per wave), partial softmax states merged through LDS,
 // z written to zheavy[slot].  The fused layer kernel copies that z instead of walking the row.
 // --------------------------------------------------------------------------------------------
+#ifndef EH_HEAVY_DEG
 #define EH_HEAVY_DEG 40
+#endif
 
 __global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, int32_t* __restrict__ counter,
                                                     int32_t* __restrict__ heavy_nodes, int32_t* __restrict__ heavy_slot) {
@@ -749,8 +751,13 @@ extern "C" int edgehip_debug_read(unsigned long long* out_host, int reset) {
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(eh_dbg), z, sizeof(z)); }
     return 0;
 }
+#define EH_SUB_BEGIN() unsigned long long t_sub = __builtin_amdgcn_s_memtime()
+#define EH_SUB_AT(k) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&eh_dbg[k], t_ - t_sub); t_sub = t_; } } while (0)
 #else
 #define EH_STAMP_AT(k) do { } while (0)
+#define EH_SUB_BEGIN() do { } while (0)
+#define EH_SUB_AT(k) do { } while (0)
 #endif
 
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
@@ -783,6 +790,21 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
+
+    // bit rows of this wave's 8 attention targets (rows k*4 + wave: interleaved over the waves so that a run
+    // of high-degree nodes does not land on one wave); issued here so the loads fly under phases 0 and A
+    const int node0 = L.node_ptr[g];
+    const int stride = L.adj_stride[g];
+    const uint32_t* gadj = a.adj + L.adj_ptr[g];
+    const bool mine8 = lane < 8 && lane * 4 + wave < rows;
+    const int hs8 = mine8 ? a.heavy_slot[row0 + lane * 4 + wave] : -1;
+    const int dg8 = mine8 ? a.deg[row0 + lane * 4 + wave] : 0;
+    uint32_t fw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
+        fw[k] = (need && lane < stride) ? gadj[(int64_t)(row0 + k * 4 + wave - node0) * stride + lane] : 0u;
+    }
 
     // ---- phase 0: h tile -> LDS (full-line loads)
 #pragma unroll
@@ -818,53 +840,66 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // iteration, every group gathering its own 256-byte row (no redundant loads), the next iteration's
     // rows in flight.  Lane (group, c) keeps channels 8c..8c+7 of qt and of the running sum for all heads.
     {
-        const int node0 = L.node_ptr[g];
-        const int stride = L.adj_stride[g];
-        const uint32_t* gadj = a.adj + L.adj_ptr[g];
         const int grp = lane >> 3, c = lane & 7;
         int* myids = idl + wave * (8 * EH_HEAVY_DEG);
-        const bool mine8 = lane < 8 && wave * 8 + lane < rows;
-        const int hs8 = mine8 ? a.heavy_slot[row0 + wave * 8 + lane] : -1;
-        const int dg8 = mine8 ? a.deg[row0 + wave * 8 + lane] : 0;
-        // (a) bit rows of the 8 targets, all loads in flight before the first is decoded
-        uint32_t fw[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
-            fw[k] = (need && lane < stride) ? gadj[(int64_t)(row0 + wave * 8 + k - node0) * stride + lane] : 0u;
-        }
-        // (b) decode each row into an ascending neighbour-id list in LDS (popcount + wave prefix sum)
+        EH_SUB_BEGIN();
+        // (b) decode the rows into ascending neighbour-id lists in LDS.  First 64 words of all 8 rows
+        //     together (popcount + wave prefix sums, the 8 scans interleaved), further words row by row.
         int mydeg = 0;
+        {
+            int cnt[8], incl[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
-            if (need) {
-                int base = 0;
-                const uint32_t* rowp = gadj + (int64_t)(row0 + wave * 8 + k - node0) * stride;
-                for (int w0 = 0; w0 < stride; w0 += 64) {
-                    uint32_t w = (w0 == 0) ? fw[k] : ((w0 + lane < stride) ? rowp[w0 + lane] : 0u);
-                    const int cnt = __popc(w);
-                    int incl = cnt;
+            for (int k = 0; k < 8; ++k) { cnt[k] = __popc(fw[k]); incl[k] = cnt[k]; }
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        int t = __shfl_up(incl, d);
-                        if (lane >= d) incl += t;
+            for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int t = __shfl_up(incl[k], d);
+                    if (lane >= d) incl[k] += t;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int base = __builtin_amdgcn_readlane(incl[k], 63);
+                int pos = incl[k] - cnt[k];
+                uint32_t w = fw[k];
+                const int jb = node0 + lane * 32;
+                while (w) {
+                    if (pos < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + pos] = jb + __ffs((int)w) - 1;
+                    ++pos;
+                    w &= w - 1;
+                }
+                if (stride > 64) {
+                    const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
+                    if (need) {
+                        const uint32_t* rowp = gadj + (int64_t)(row0 + k * 4 + wave - node0) * stride;
+                        for (int w0 = 64; w0 < stride; w0 += 64) {
+                            uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+                            const int c2 = __popc(w2);
+                            int in2 = c2;
+#pragma unroll
+                            for (int d = 1; d < 64; d <<= 1) {
+                                int t = __shfl_up(in2, d);
+                                if (lane >= d) in2 += t;
+                            }
+                            int p2 = base + in2 - c2;
+                            const int jb2 = node0 + (w0 + lane) * 32;
+                            while (w2) {
+                                if (p2 < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + p2] = jb2 + __ffs((int)w2) - 1;
+                                ++p2;
+                                w2 &= w2 - 1;
+                            }
+                            base += __builtin_amdgcn_readlane(in2, 63);
+                        }
                     }
-                    int pos = base + incl - cnt;
-                    const int jb = node0 + (w0 + lane) * 32;
-                    while (w) {
-                        if (pos < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + pos] = jb + __ffs((int)w) - 1;
-                        ++pos;
-                        w &= w - 1;
-                    }
-                    base += __builtin_amdgcn_readlane(incl, 63);
                 }
                 if (grp == k) mydeg = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
             }
         }
         EH_LDS_SYNC();
+        EH_SUB_AT(8);
         // (c) the 8 targets advance together
-        const int trow = wave * 8 + grp;
+        const int trow = grp * 4 + wave;
         const int self = row0 + (trow < rows ? trow : rows - 1);
         float* qrow = qz + trow * QP + c * 8;
         float q[HEADS][8], acc[HEADS][8], mh[HEADS], lh[HEADS];
@@ -875,6 +910,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             for (int d = 0; d < 4; ++d) { q[h][d] = q0[d]; q[h][4 + d] = q1[d]; acc[h][d] = 0.f; acc[h][4 + d] = 0.f; }
             mh[h] = -1e30f; lh[h] = 0.f;      // finite floor: exp(-1e30 - x) = 0 and never inf - inf
         }
+        EH_SUB_AT(9);
         const int* lst = myids + grp * EH_HEAVY_DEG;
         auto loadx = [&](int i, f32x4& x0, f32x4& x1) {
             const int id = (i < mydeg) ? lst[i] : self;
@@ -918,6 +954,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 }
             }
         }
+        EH_SUB_AT(10);
         // (d) z -> LDS (heavy rows: the block-per-row kernel already computed it)
         const int hslot = __shfl(hs8, grp);
 #pragma unroll
@@ -934,6 +971,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             *reinterpret_cast<f32x4*>(qrow + h * 64) = o0;
             *reinterpret_cast<f32x4*>(qrow + h * 64 + 4) = o1;
         }
+        EH_SUB_AT(11);
     }
     __syncthreads();
     EH_STAMP_AT(2);

@@ -66,6 +66,9 @@ def main():
         tot_c = sum(buf[:7]) or 1
         names = ['0 load h', 'A qt', 'B attention', 'C conv mma', 'C reduce', 'D gru', 'E ctx']
         print('  k_layer phase shares (wave 0 cycles):', ', '.join(f'{n} {100 * buf[i] / tot_c:.1f}%' for i, n in enumerate(names)))
+        sub = ['B.decode', 'B.q load', 'B.walk', 'B.z write']
+        print('  inside B (wave 0):', ', '.join(f'{n} {100 * buf[8 + i] / tot_c:.1f}%' for i, n in enumerate(sub)),
+              f'; barrier wait {100 * (buf[2] - sum(buf[8:12])) / tot_c:.1f}%')
 
 
 if __name__ == '__main__':
