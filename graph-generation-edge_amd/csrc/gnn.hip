@@ -661,62 +661,181 @@ __global__ __launch_bounds__(256) void k_heavy_qbias(edgehip_layout L, int H, co
     }
 }
 
+// Walk one decoded neighbour list (ids in LDS, padded with filler ids to a whole step) for ONE target,
+// continuing the online-softmax state (m, l, acc).  Lane = (slot, head, c): channels 8c..8c+7 of one head;
+// HEADS < 8 runs 8/HEADS neighbours side by side (slots; merged by the caller with eh_merge_slots).
+// U rounds per step: scores of the step first, one rescale, then the weighted sum; the rows of the next
+// step are in flight while the current one is consumed (two register sets).
 template <int HEADS>
-__global__ __launch_bounds__(256, 3) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
-                                                       const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
-                                                       const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
-                                                       float* __restrict__ zheavy) {
+struct eh_walk_cfg {
+    static constexpr int NSLOT = 8 / HEADS;
+    static constexpr int U = (HEADS == 8) ? 4 : (HEADS == 4 ? 2 : 1);
+    static constexpr int UN = U * NSLOT;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one neighbour row chunk of a lane: channels 8c..8c+7 as four float pairs
+struct eh_x8 { f32x2 p[4]; };
+
+// Lists hold BYTE offsets of the neighbour rows (id * 256): the gather is `base + offset` with a 32-bit
+// offset (scalar base, no 64-bit address arithmetic per visit).
+__device__ static inline void eh_gather8(eh_x8& x, const float* __restrict__ hsrc, uint32_t row_off, int c) {
+    const f32x4* xp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * 32u));
+    const f32x4 a = xp[0], b = xp[1];
+    x.p[0] = f32x2{a[0], a[1]}; x.p[1] = f32x2{a[2], a[3]}; x.p[2] = f32x2{b[0], b[1]}; x.p[3] = f32x2{b[2], b[3]};
+}
+
+// One step of the online softmax over U rounds (x[u] = this lane's slot's neighbour of round u).
+// nvalid: real visits left in the list at this step (>= UN: no masking needed).
+template <int HEADS>
+__device__ static inline void eh_walk_step(const f32x2 (&q)[4], const eh_x8 (&x)[eh_walk_cfg<HEADS>::U], int nvalid, int slot,
+                                           f32x2 (&acc)[4], float& m, float& lsum) {
+    constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
+    float sc[U];
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        f32x2 t2 = q[0] * x[u].p[0];
+        t2 = __builtin_elementwise_fma(q[1], x[u].p[1], t2);
+        t2 = __builtin_elementwise_fma(q[2], x[u].p[2], t2);
+        t2 = __builtin_elementwise_fma(q[3], x[u].p[3], t2);
+        sc[u] = eh_group8_sum(t2[0] + t2[1]);
+    }
+    if (nvalid < UN) {                       // wave-uniform: only the last step of a list has filler visits
+#pragma unroll
+        for (int u = 0; u < U; ++u) sc[u] = (u * NSLOT + slot < nvalid) ? sc[u] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
+    const float resc = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { sc[u] = __expf(sc[u] - mn); ps += sc[u]; }
+    lsum = lsum * resc + ps;
+    const f32x2 r2 = f32x2{resc, resc};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[d] *= r2;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const f32x2 p2 = f32x2{sc[u], sc[u]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = __builtin_elementwise_fma(p2, x[u].p[d], acc[d]);
+    }
+    m = mn;
+}
+
+template <int HEADS>
+__device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
+                                           const f32x2 (&q)[4], int lane, f32x2 (&acc)[4], float& m, float& lsum) {
+    constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
+    const int grp = lane >> 3, c = lane & 7;
+    const int slot = grp / HEADS;
+    const int nsteps = (nvis + UN - 1) / UN;
+    if (nsteps == 0) return;
+    auto fetch = [&](int gs, eh_x8 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) eh_gather8(x[u], hsrc, list[(gs * U + u) * NSLOT + slot], c);
+    };
+    eh_x8 xa[U], xb[U];
+    const int lastg = nsteps - 1;
+    // sched_barrier: the scheduler otherwise sinks the prefetch loads next to their first use (the next
+    // compute), which turns the pipeline into load -> wait -> compute
+    fetch(0, xa);
+#pragma unroll 1
+    for (int gs = 0; gs < nsteps; gs += 2) {
+        fetch(gs + 1 < lastg ? gs + 1 : lastg, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        eh_walk_step<HEADS>(q, xa, nvis - gs * UN, slot, acc, m, lsum);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gs + 1 >= nsteps) break;
+        fetch(gs + 2 < lastg ? gs + 2 : lastg, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        eh_walk_step<HEADS>(q, xb, nvis - (gs + 1) * UN, slot, acc, m, lsum);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// merge the online-softmax states of the 8/HEADS slots (all lanes end with the merged state)
+template <int HEADS>
+__device__ static inline void eh_merge_slots(f32x2 (&acc)[4], float& m, float& lsum) {
+#pragma unroll
+    for (int o = 8 * HEADS; o < 64; o <<= 1) {
+        const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(lsum, o);
+        const float mm = fmaxf(m, m2);
+        const float s1 = __expf(m - mm), s2 = __expf(m2 - mm);
+        lsum = lsum * s1 + l2 * s2;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a0 = __shfl_xor(acc[d][0], o), a1 = __shfl_xor(acc[d][1], o);
+            acc[d][0] = acc[d][0] * s1 + a0 * s2;
+            acc[d][1] = acc[d][1] * s1 + a1 * s2;
+        }
+        m = mm;
+    }
+}
+
+// Heavy rows: ONE WAVE per row, no block-level synchronisation.  Per 64-word chunk of the bit row the wave
+// decodes the neighbour ids into its LDS list (popcount + prefix sum) and walks them with eh_walk_list.
+template <int HEADS>
+__global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
+                                                    const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
+                                                    const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
+                                                    float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
-    __shared__ float ms[4][8], ls[4][8];
-    __shared__ __attribute__((aligned(16))) float accs[4][64][8];
-    __shared__ int idl[4][512];                                        // neighbour ids of one 16-word sub-chunk
-    __shared__ __attribute__((aligned(16))) float rng[4][8 * 64];      // staged rows of h
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    constexpr int UN = eh_walk_cfg<HEADS>::UN;
+    __shared__ uint32_t lists[4][2048 + 8];        // a 64-word chunk holds at most 2048 neighbours (+ step padding)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nheavy = *counter;
-    for (int idx = blockIdx.x; idx < nheavy; idx += gridDim.x) {
+    uint32_t* list = lists[wave];
+    const int grp = lane >> 3, c = lane & 7;
+    const int slot = grp / HEADS, head = grp % HEADS;
+    // XCD affinity: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the contiguous slice
+    // [x*nheavy/8, (x+1)*nheavy/8) of the list, which is roughly in node order, so an XCD touches the h rows
+    // of ~B/8 graphs (a few MB: L2-resident) instead of all of them.  Affinity only; any placement is correct.
+    const int xcd = blockIdx.x & 7, nloc = (gridDim.x + 7 - xcd) >> 3;      // blocks of this XCD
+    const int s0 = (int)((int64_t)nheavy * xcd / 8), s1 = (int)((int64_t)nheavy * (xcd + 1) / 8);
+    for (int idx = s0 + (blockIdx.x >> 3) * 4 + wave; idx < s1; idx += nloc * 4) {
         const int node = heavy_nodes[idx];
         const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
         const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
-        __syncthreads();                       // previous iteration's LDS is consumed
-        const int grp = lane >> 3, c = lane & 7;
-        const int head = grp % HEADS;
-        float q[8], acc[8], m, lsum;
+        f32x2 q[4], acc[4];
+        float m = -1e30f, lsum = 0.f;
         {
             const f32x4* qp = reinterpret_cast<const f32x4*>(qheavy + (size_t)idx * H + head * 64 + c * 8);
-            f32x4 q0 = qp[0], q1 = qp[1];
+            const f32x4 q0 = qp[0], q1 = qp[1];
+            q[0] = f32x2{q0[0], q0[1]}; q[1] = f32x2{q0[2], q0[3]}; q[2] = f32x2{q1[0], q1[1]}; q[3] = f32x2{q1[2], q1[3]};
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { q[d] = q0[d]; q[4 + d] = q1[d]; }
+            for (int d = 0; d < 4; ++d) acc[d] = f32x2{0.f, 0.f};
         }
-        const int per = (stride + 3) / 4;
-        const int wb = wave * per, we = (wb + per < stride) ? wb + per : stride;
-        const uint32_t fw = (wb + lane < we) ? rowp[wb + lane] : 0u;
-        eh_attend_raw<HEADS, 16, 8>(rowp, wb, we, fw, node0, hsrc, q, lane, acc, m, lsum, idl[wave], rng[wave]);
-        if (c == 0 && grp < HEADS) { ms[wave][head] = m; ls[wave][head] = lsum; }
+        for (int w0 = 0; w0 < stride; w0 += 64) {
+            uint32_t w = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+            const int cnt = __popc(w);
+            int incl = cnt;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) accs[wave][lane][d] = acc[d];
-        __syncthreads();
-        if (wave == 0 && grp < HEADS) {         // fixed merge order: wave 0..3
-            float M = fmaxf(fmaxf(ms[0][head], ms[1][head]), fmaxf(ms[2][head], ms[3][head]));
-            float Lsum = 0.f, out[8];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) out[d] = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                float mw = ms[w][head];
-                float sc = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-                Lsum += ls[w][head] * sc;
-#pragma unroll
-                for (int d = 0; d < 8; ++d) out[d] += accs[w][lane][d] * sc;
+            for (int d = 1; d < 64; d <<= 1) {
+                int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
             }
-            float inv = 1.0f / (Lsum + 1e-16f);
-            f32x4 o0, o1;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { o0[d] = out[d] * inv; o1[d] = out[4 + d] * inv; }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) continue;
+            int pos = incl - cnt;
+            const uint32_t jb = (uint32_t)(node0 + (w0 + lane) * 32);
+            while (w) { list[pos++] = (jb + (uint32_t)__ffs((int)w) - 1u) * 256u; w &= w - 1; }
+            if (lane < UN) list[total + lane] = (uint32_t)node * 256u;   // filler visits of the last step (masked)
+            EH_LDS_SYNC();
+            eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, lsum);
+            EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
+        }
+        eh_merge_slots<HEADS>(acc, m, lsum);
+        if (slot == 0) {
+            const float inv = 1.0f / (lsum + 1e-16f);
             f32x4* zp = reinterpret_cast<f32x4*>(zheavy + (size_t)idx * H + head * 64 + c * 8);
-            zp[0] = o0; zp[1] = o1;
+            zp[0] = f32x4{acc[0][0] * inv, acc[0][1] * inv, acc[1][0] * inv, acc[1][1] * inv};
+            zp[1] = f32x4{acc[2][0] * inv, acc[2][1] * inv, acc[3][0] * inv, acc[3][1] * inv};
         }
     }
 }
@@ -836,16 +955,24 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     EH_STAMP_AT(1);
 
     // ---- phase B: attention of the light rows, z overwrites qt.
-    // One 8-lane group per TARGET: a wave advances its 8 targets together, one neighbour each per
-    // iteration, every group gathering its own 256-byte row (no redundant loads), the next iteration's
-    // rows in flight.  Lane (group, c) keeps channels 8c..8c+7 of qt and of the running sum for all heads.
+    // A wave owns 8 targets (rows k*4 + wave) and walks them as ONE flat stream of neighbour visits: the
+    // decoded neighbour lists are concatenated in LDS (each padded to a whole step), so the gathers of the
+    // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
+    // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
+    // neighbours side by side (slots) and merges their softmax states when the target ends.
     {
+        constexpr int NSLOT = 8 / HEADS;
+        constexpr int U = (HEADS == 8) ? 4 : (HEADS == 4 ? 2 : 1);     // rounds per step
+        constexpr int UN = U * NSLOT;                                  // visits per step (divides EH_HEAVY_DEG)
+        static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
         const int grp = lane >> 3, c = lane & 7;
-        int* myids = idl + wave * (8 * EH_HEAVY_DEG);
+        const int slot = grp / HEADS, head = grp % HEADS;
+        uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (8 * EH_HEAVY_DEG);
         EH_SUB_BEGIN();
         // (b) decode the rows into ascending neighbour-id lists in LDS.  First 64 words of all 8 rows
         //     together (popcount + wave prefix sums, the 8 scans interleaved), further words row by row.
-        int mydeg = 0;
+        int wdeg = 0;             // lane k < 8: neighbours of target k walked here (0: isolated or heavy)
+        int total_steps = 0;      // wave-uniform
         {
             int cnt[8], incl[8];
 #pragma unroll
@@ -858,6 +985,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                     if (lane >= d) incl[k] += t;
                 }
             }
+            int off = 0;          // wave-uniform: start of target k's (padded) list
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 int base = __builtin_amdgcn_readlane(incl[k], 63);
@@ -865,7 +993,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 uint32_t w = fw[k];
                 const int jb = node0 + lane * 32;
                 while (w) {
-                    if (pos < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + pos] = jb + __ffs((int)w) - 1;
+                    if (pos < EH_HEAVY_DEG) flat[off + pos] = (uint32_t)(jb + __ffs((int)w) - 1) * 256u;
                     ++pos;
                     w &= w - 1;
                 }
@@ -885,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                             int p2 = base + in2 - c2;
                             const int jb2 = node0 + (w0 + lane) * 32;
                             while (w2) {
-                                if (p2 < EH_HEAVY_DEG) myids[k * EH_HEAVY_DEG + p2] = jb2 + __ffs((int)w2) - 1;
+                                if (p2 < EH_HEAVY_DEG) flat[off + p2] = (uint32_t)(jb2 + __ffs((int)w2) - 1) * 256u;
                                 ++p2;
                                 w2 &= w2 - 1;
                             }
@@ -893,83 +1021,87 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                         }
                     }
                 }
-                if (grp == k) mydeg = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
+                base = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
+                const int padded = (base + UN - 1) / UN * UN;
+                if (base + lane < padded) flat[off + base + lane] = (uint32_t)(row0 + k * 4 + wave) * 256u;    // masked filler visits
+                if (lane == k) wdeg = base;
+                off += padded;
+                total_steps += padded / UN;
             }
         }
         EH_LDS_SYNC();
         EH_SUB_AT(8);
-        // (c) the 8 targets advance together
-        const int trow = grp * 4 + wave;
-        const int self = row0 + (trow < rows ? trow : rows - 1);
-        float* qrow = qz + trow * QP + c * 8;
-        float q[HEADS][8], acc[HEADS][8], mh[HEADS], lh[HEADS];
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-            f32x4 q0 = *reinterpret_cast<const f32x4*>(qrow + h * 64), q1 = *reinterpret_cast<const f32x4*>(qrow + h * 64 + 4);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { q[h][d] = q0[d]; q[h][4 + d] = q1[d]; acc[h][d] = 0.f; acc[h][4 + d] = 0.f; }
-            mh[h] = -1e30f; lh[h] = 0.f;      // finite floor: exp(-1e30 - x) = 0 and never inf - inf
-        }
-        EH_SUB_AT(9);
-        const int* lst = myids + grp * EH_HEAVY_DEG;
-        auto loadx = [&](int i, f32x4& x0, f32x4& x1) {
-            const int id = (i < mydeg) ? lst[i] : self;
-            const f32x4* xp = reinterpret_cast<const f32x4*>(a.hprev + (size_t)id * 64 + c * 8);
-            x0 = xp[0]; x1 = xp[1];
-        };
-        auto update = [&](bool valid, const f32x4& x0, const f32x4& x1) {
-#pragma unroll
-            for (int h = 0; h < HEADS; ++h) {
-                float t = 0.f;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) t += q[h][d] * x0[d] + q[h][4 + d] * x1[d];
-                t = eh_group8_sum(t);
-                t = valid ? t : -INFINITY;
-                const float mn = fmaxf(mh[h], t);
-                const float resc = __expf(mh[h] - mn);
-                const float p = __expf(t - mn);
-                lh[h] = lh[h] * resc + p;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    acc[h][d] = acc[h][d] * resc + p * x0[d];
-                    acc[h][4 + d] = acc[h][4 + d] * resc + p * x1[d];
-                }
-                mh[h] = mn;
-            }
-        };
+        // (c) the flat walk
         {
-            f32x4 xa0, xa1, xb0, xb1;
-            int it = 0;
-            if (__any(mydeg > 0)) {
-                loadx(0, xa0, xa1);
-                while (true) {
-                    loadx(it + 1, xb0, xb1);
-                    update(it < mydeg, xa0, xa1);
-                    ++it;
-                    if (!__any(it < mydeg)) break;
-                    loadx(it + 1, xa0, xa1);
-                    update(it < mydeg, xb0, xb1);
-                    ++it;
-                    if (!__any(it < mydeg)) break;
+            f32x2 q[4], acc[4];
+            float mrun = -1e30f, lrun = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
+            int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
+            auto fetch = [&](int gs, eh_x8 (&x)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) eh_gather8(x[u], a.hprev, flat[(gs * U + u) * NSLOT + slot], c);
+            };
+            auto compute = [&](const eh_x8 (&x)[U]) {
+                if (st == nst) {                         // next target with work
+                    do {
+                        ++k;
+                        dk = __builtin_amdgcn_readlane(wdeg, k);
+                        nst = (dk + UN - 1) / UN;
+                    } while (nst == 0);
+                    st = 0;
+                    const float* qrow = qz + (k * 4 + wave) * QP + head * 64 + c * 8;
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qrow), q1 = *reinterpret_cast<const f32x4*>(qrow + 4);
+                    q[0] = f32x2{q0[0], q0[1]}; q[1] = f32x2{q0[2], q0[3]}; q[2] = f32x2{q1[0], q1[1]}; q[3] = f32x2{q1[2], q1[3]};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[d] = f32x2{0.f, 0.f};
+                    mrun = -1e30f; lrun = 0.f;            // finite floor: exp(-1e30 - x) = 0 and never inf - inf
+                }
+                eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, lrun);
+                ++st;
+                if (st == nst) {                         // target finished: merge the slots, write z over its qt row
+                    eh_merge_slots<HEADS>(acc, mrun, lrun);
+                    if (slot == 0) {
+                        const float inv = 1.0f / (lrun + 1e-16f);
+                        float* zrow = qz + (k * 4 + wave) * QP + head * 64 + c * 8;
+                        *reinterpret_cast<f32x4*>(zrow) = f32x4{acc[0][0] * inv, acc[0][1] * inv, acc[1][0] * inv, acc[1][1] * inv};
+                        *reinterpret_cast<f32x4*>(zrow + 4) = f32x4{acc[2][0] * inv, acc[2][1] * inv, acc[3][0] * inv, acc[3][1] * inv};
+                    }
+                }
+            };
+            if (total_steps > 0) {
+                eh_x8 xa[U], xb[U];
+                const int lastg = total_steps - 1;
+                fetch(0, xa);
+#pragma unroll 1
+                for (int gs = 0; gs < total_steps; gs += 2) {
+                    fetch(gs + 1 < lastg ? gs + 1 : lastg, xb);
+                    compute(xa);
+                    if (gs + 1 >= total_steps) break;
+                    fetch(gs + 2 < lastg ? gs + 2 : lastg, xa);
+                    compute(xb);
                 }
             }
         }
         EH_SUB_AT(10);
-        // (d) z -> LDS (heavy rows: the block-per-row kernel already computed it)
-        const int hslot = __shfl(hs8, grp);
+        // (d) targets not walked here: isolated -> z = 0, heavy -> the block-per-row kernel computed z.
+        //     Group-per-target layout: lane (target grp, c) moves channels 8c..8c+7 of every head.
+        {
+            const int tdeg = __shfl(wdeg, grp);
+            const int hslot = __shfl(hs8, grp);
+            if (tdeg == 0) {
+                float* zrow = qz + (grp * 4 + wave) * QP + c * 8;
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-            f32x4 o0, o1;
-            if (hslot >= 0) {
-                const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + h * 64 + c * 8);
-                o0 = zp[0]; o1 = zp[1];
-            } else {
-                const float inv = 1.0f / (lh[h] + 1e-16f);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) { o0[d] = acc[h][d] * inv; o1[d] = acc[h][4 + d] * inv; }
+                for (int h = 0; h < HEADS; ++h) {
+                    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+                    if (hslot >= 0) {
+                        const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + h * 64 + c * 8);
+                        o0 = zp[0]; o1 = zp[1];
+                    }
+                    *reinterpret_cast<f32x4*>(zrow + h * 64) = o0;
+                    *reinterpret_cast<f32x4*>(zrow + h * 64 + 4) = o1;
+                }
             }
-            *reinterpret_cast<f32x4*>(qrow + h * 64) = o0;
-            *reinterpret_cast<f32x4*>(qrow + h * 64 + 4) = o1;
         }
         EH_SUB_AT(11);
     }
@@ -1143,6 +1275,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     eh_fold_map fm = eh_make_fold_map(P);
     const int B = L->num_graphs, Nn = L->num_nodes, NT = L->num_tiles;
     if (B == 0 || Nn == 0) return EDGEHIP_OK;
+    if ((int64_t)Nn * 256 > 0xFFFFFFFFll) return EDGEHIP_ERR_UNSUPPORTED;   // neighbour rows are addressed by 32-bit byte offsets
     const int tile_blocks = (NT + 3) / 4;
     int hmax = 1;
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
