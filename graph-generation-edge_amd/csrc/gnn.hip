@@ -213,7 +213,7 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.Mb = (float*)take(NnP * 64 * 4);
     w.part = (float*)take((NT + 1) * 256 * 4);
     w.te = (float*)take((B + 1) * EDGEHIP_MAX_LAYERS * 64 * 4);
-    w.ctx = (float*)take((B + 1) * 64 * 4);
+    w.ctx = (float*)take((size_t)2 * (B + 1) * 64 * 4);    // two copies: layer l reads one, writes the other
     w.qbias = (float*)take((B + 1) * H * 4);
     w.obias0 = (float*)take((B + 1) * 64 * 4); w.obias1 = (float*)take((B + 1) * 64 * 4);
     w.cbias = (float*)take((B + 1) * 256 * 4);
@@ -314,87 +314,6 @@ struct eh_layer_ptrs {
     int H;
 };
 
-__global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, int l, eh_layer_ptrs lp,
-                                                      const float* __restrict__ part, const float* __restrict__ te,
-                                                      int te_shared, float* __restrict__ ctx, float* __restrict__ qbias,
-                                                      int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
-                                                      float* __restrict__ cbias) {
-    __shared__ float mean[256], v[64], hid[256], cn[64], tev[64];
-    int g = blockIdx.x, tid = threadIdx.x;
-    int n = L.node_ptr[g + 1] - L.node_ptr[g];
-    int t0 = L.tile_ptr[g], t1 = L.tile_ptr[g + 1];
-    int width = (l == 0) ? 64 : 256;
-    if (tid < width) {
-        float s = 0.f;
-        for (int t = t0; t < t1; ++t) s += part[(size_t)t * 256 + tid];
-        mean[tid] = s / (float)(n > 0 ? n : 1);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        if (l == 0) {
-            v[tid] = mean[tid];
-        } else {
-            const float* w = P.context_w2 + (size_t)tid * 256;
-            float s = P.context_b2[tid];
-            for (int k = 0; k < 256; ++k) s += w[k] * mean[k];
-            v[tid] = ctx[(size_t)g * 64 + tid] + s;
-        }
-    }
-    __syncthreads();
-    {
-        const float* w = P.global_w0 + (size_t)tid * 64;
-        float s = P.global_b0[tid];
-        for (int k = 0; k < 64; ++k) s += w[k] * v[k];
-        hid[tid] = eh_silu(s);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const float* w = P.global_w2 + (size_t)tid * 256;
-        float s = P.global_b2[tid];
-        for (int k = 0; k < 256; ++k) s += w[k] * hid[k];
-        cn[tid] = s;
-        ctx[(size_t)g * 64 + tid] = s;
-        if (l < P.num_layers) tev[tid] = te[((size_t)(te_shared ? 0 : g) * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
-    }
-    __syncthreads();
-    if (l >= P.num_layers) return;
-    const bool addx = l > 0;    // layer 0 sees x = h0 (no context added yet)
-    for (int o = tid; o < lp.H; o += 256) {
-        const float* m = lp.Mcat + (size_t)o * 64;
-        const float* mt = lp.Mtcat + (size_t)o * 64;
-        float s = lp.mbcat[o];
-        for (int k = 0; k < 64; ++k) s += mt[k] * tev[k];
-        if (addx) for (int k = 0; k < 64; ++k) s += m[k] * cn[k];
-        qbias[(size_t)g * ldq + o] = s;
-    }
-    if (tid < 64) {
-        const float* sw = lp.skip_w + (size_t)tid * 128;
-        float s = lp.skip_b[tid];
-        for (int k = 0; k < 64; ++k) s += sw[64 + k] * tev[k];
-        if (addx) for (int k = 0; k < 64; ++k) s += sw[k] * cn[k];
-        obias0[(size_t)g * 64 + tid] = s;
-    } else if (tid < 128) {
-        int c = tid - 64;
-        float s = lp.bvbar[c];
-        for (int k = 0; k < 64; ++k) s += lp.Vbbar[c * 64 + k] * tev[k];
-        if (addx) for (int k = 0; k < 64; ++k) s += lp.Vsum[c * 64 + k] * cn[k];
-        obias1[(size_t)g * 64 + c] = s;
-    }
-    {
-        const float* w = P.context_w0 + (size_t)tid * 128 + 64;
-        float s = P.context_b0[tid];
-        for (int k = 0; k < 64; ++k) s += w[k] * cn[k];
-        cbias[(size_t)g * 256 + tid] = s;
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// attention over the bit-matrix row of each target node (one wave per node).
-// lane = 8*group + chunk: chunk c owns channels 8c..8c+7; group = slot*HEADS + head.  HEADS=8: the
-// 8 groups are the 8 heads of ONE neighbour; HEADS<8: 8/HEADS neighbours are processed at once and
-// their online-softmax states merged at the end.  Neighbour ids are popped from the row words with
-// scalar bit ops (ascending j, like the reference's edge order).
-// --------------------------------------------------------------------------------------------
 // 8-lane group reductions with DPP (no LDS crossbar): quad xor-1, quad xor-2, then half-row mirror.
 __device__ static inline float eh_dpp_f(float v, const int ctrl_sel) {
     int t;
@@ -410,6 +329,145 @@ __device__ static inline float eh_group8_sum(float v) {
     return v;
 }
 
+// Block-cooperative GEMV for the per-graph vectors: y[o] = bias[o] + W1[o,:K1] . x1 (+ W2[o,:64] . x2).
+// 16 lanes per output row, one float4 per lane and 64-wide chunk: every wave-level load covers four
+// complete 256-byte rows (thread-per-row reads touched 64 cache lines per instruction and made this
+// latency-bound kernel 3x slower).  x vectors live in LDS.  Outputs o = first + 16*pass + 4*wave + sub.
+__device__ static inline float eh_row16_sum(float v) {
+    v += eh_dpp_f(v, 0);                                                                    // xor 1
+    v += eh_dpp_f(v, 1);                                                                    // xor 2
+    v += eh_dpp_f(v, 2);                                                                    // half-row mirror (8)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row mirror (16)
+    return v;
+}
+template <int K1, bool TWO>
+__device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld1, const float* __restrict__ x1,
+                                            const float* __restrict__ W2, int ld2, const float* __restrict__ x2,
+                                            const float* __restrict__ bias, int first, int count, float* __restrict__ y,
+                                            int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, kq = lane & 15;
+    f32x4 xa[K1 / 64], xb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K1 / 64; ++j) xa[j] = *reinterpret_cast<const f32x4*>(x1 + 64 * j + 4 * kq);
+    if (TWO) xb = *reinterpret_cast<const f32x4*>(x2 + 4 * kq);
+    // PB passes (16 outputs each) per trip, all their loads (16 float4 per lane) issued before the first
+    // reduction: a trip costs one L2 round trip
+    constexpr int PB = 16 / (K1 / 64 + (TWO ? 1 : 0));
+    for (int o0 = first + 4 * wave + sub; o0 < first + count; o0 += 16 * PB) {
+        f32x4 w1[PB][K1 / 64], w2[PB];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int o = o0 + 16 * p;
+            const int oc = o < first + count ? o : o0;            // clamp: a valid row, result discarded
+#pragma unroll
+            for (int j = 0; j < K1 / 64; ++j)
+                w1[p][j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)oc * ld1 + 64 * j + 4 * kq);
+            if (TWO) w2[p] = *reinterpret_cast<const f32x4*>(W2 + (size_t)oc * ld2 + 4 * kq);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int o = o0 + 16 * p;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < K1 / 64; ++j)
+                s += w1[p][j][0] * xa[j][0] + w1[p][j][1] * xa[j][1] + w1[p][j][2] * xa[j][2] + w1[p][j][3] * xa[j][3];
+            if (TWO) s += w2[p][0] * xb[0] + w2[p][1] * xb[1] + w2[p][2] * xb[2] + w2[p][3] * xb[3];
+            s = eh_row16_sum(s);
+            if (kq == 0 && o < first + count) {
+                s += bias ? bias[o] : 0.f;
+                y[o] = act ? eh_silu(s) : s;
+            }
+        }
+    }
+}
+
+// grid (B, EH_GU_PARTS): every part recomputes the (cheap) context chain, then takes its share of the
+// per-graph bias vectors of layer l, so that 4 x B blocks are in flight instead of B.
+#define EH_GU_PARTS 4
+__global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, int l, eh_layer_ptrs lp,
+                                                      const float* __restrict__ part, const float* __restrict__ te,
+                                                      int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
+                                                      int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
+                                                      float* __restrict__ cbias) {
+    __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
+    const int g = blockIdx.x, prt = blockIdx.y, tid = threadIdx.x;
+    const int n = L.node_ptr[g + 1] - L.node_ptr[g];
+    const int t0 = L.tile_ptr[g], t1 = L.tile_ptr[g + 1];
+    const int width = (l == 0) ? 64 : 256;
+    if (tid < width) {
+        // eight independent partial sums: the tile loads of a trip are all in flight together (a plain
+        // `s += part[..]` loop waits for every load in turn: ~40 L2 round trips per launch)
+        float ps[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps[j] = 0.f;
+        int t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = part[(size_t)(t + j) * 256 + tid];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps[j] += x[j];
+        }
+        {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps[j] += x[j];
+        }
+        const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+        mean[tid] = s / (float)(n > 0 ? n : 1);
+    }
+    if (tid < 64) {
+        zero64[tid] = 0.f;
+        if (l < P.num_layers) tev[tid] = te[((size_t)(te_shared ? 0 : g) * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
+    }
+    __syncthreads();
+    if (l == 0) {
+        if (tid < 64) v[tid] = mean[tid];
+    } else {
+        const float cold = tid < 64 ? ctx_in[(size_t)g * 64 + tid] : 0.f;      // in flight under the GEMV
+        eh_block_gemv<256, false>(P.context_w2, 256, mean, nullptr, 0, nullptr, P.context_b2, 0, 64, v, 0);
+        __syncthreads();
+        if (tid < 64) v[tid] += cold;
+    }
+    __syncthreads();
+    eh_block_gemv<64, false>(P.global_w0, 64, v, nullptr, 0, nullptr, P.global_b0, 0, 256, hid, 1);
+    __syncthreads();
+    eh_block_gemv<256, false>(P.global_w2, 256, hid, nullptr, 0, nullptr, P.global_b2, 0, 64, cn, 0);
+    __syncthreads();
+    // the parts of a graph are independent blocks: the old context is read from ctx_in and the new one goes
+    // to the other copy (ctx), so a late part never sees a half-updated value
+    if (l >= P.num_layers) {
+        if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+        return;
+    }
+    const float* xc = (l > 0) ? cn : zero64;      // layer 0 sees x = h0 (no context added yet)
+    {   // qbias[o] = mbcat[o] + Mtcat[o,:] . te + Mcat[o,:] . ctx      share of this part
+        const int per = ((lp.H / 16 + EH_GU_PARTS - 1) / EH_GU_PARTS) * 16;
+        const int first = prt * per;
+        const int count = first + per <= lp.H ? per : (lp.H > first ? lp.H - first : 0);
+        eh_block_gemv<64, true>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
+    }
+    {   // cbias = context_b0 + context_w0[:, 64:128] . ctx             64 rows per part
+        eh_block_gemv<64, false>(P.context_w0 + 64, 128, cn, nullptr, 0, nullptr, P.context_b0, prt * 64, 64,
+                                 cbias + (size_t)g * 256, 0);
+    }
+    if (prt == 1)       // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx
+        eh_block_gemv<64, true>(lp.skip_w + 64, 128, tev, lp.skip_w, 128, xc, lp.skip_b, 0, 64, obias0 + (size_t)g * 64, 0);
+    if (prt == 2)       // obias1 = bvbar + Vbbar . te + Vsum . ctx
+        eh_block_gemv<64, true>(lp.Vbbar, 64, tev, lp.Vsum, 64, xc, lp.bvbar, 0, 64, obias1 + (size_t)g * 64, 0);
+    if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+}
+
+// --------------------------------------------------------------------------------------------
+// attention over the bit-matrix row of each target node (one wave per node).
+// lane = 8*group + chunk: chunk c owns channels 8c..8c+7; group = slot*HEADS + head.  HEADS=8: the
+// 8 groups are the 8 heads of ONE neighbour; HEADS<8: 8/HEADS neighbours are processed at once and
+// their online-softmax states merged at the end.  Neighbour ids are popped from the row words with
+// scalar bit ops (ascending j, like the reference's edge order).
+// --------------------------------------------------------------------------------------------
 // One target node (or a word range of its row).  Per 64-word chunk of the bit-matrix row:
 //   1. decode: every lane holds one word; popcount + wave prefix sum give each lane its place in an
 //      ascending neighbour-id list in LDS (vector ops - a scalar pop per neighbour cost ~25 SALU each);
@@ -1297,7 +1355,8 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             lp.Vbbar = folded + f.Vbbar; lp.bvbar = folded + f.bvbar; lp.Vsum = folded + f.Vsum;
             lp.skip_w = P->skip_w[l]; lp.skip_b = P->skip_b[l]; lp.H = P->heads[l] * 64;
         }
-        EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B), dim3(256), 0, s, *L, *P, l, lp, w.part, w.te, t_shared, w.ctx,
+        EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, w.te, t_shared,
+                           w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64, w.ctx + (size_t)(l & 1) * (B + 1) * 64,
                            w.qbias, ldq, w.obias0, w.obias1, w.cbias));
         if (l == P->num_layers) break;
         const int h = P->heads[l];
@@ -1340,7 +1399,8 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         (void)hipMemcpyAsync(h_out, hcur, (size_t)Nn * 64 * 4, hipMemcpyDeviceToDevice, s);
     }
     // tail on the active nodes
-    EH_PROF(EH_K_GATHER, s, hipLaunchKernelGGL(k_gather_active, dim3(tile_blocks), dim3(256), 0, s, *L, *P, act_nodes, kptr, hcur, w.ctx, deg,
+    EH_PROF(EH_K_GATHER, s, hipLaunchKernelGGL(k_gather_active, dim3(tile_blocks), dim3(256), 0, s, *L, *P, act_nodes, kptr, hcur,
+                       w.ctx + (size_t)(P->num_layers & 1) * (B + 1) * 64, deg,
                        d0, w.Xact));
     eh_gemm_desc g0 = {};
     g0.A = w.Xact; g0.lda = 256; g0.K1 = 256; g0.W = folded + fm.pNo0; g0.w_packed = 1; g0.K = 256; g0.N = 128; g0.bias = P->node_out_b0;
