@@ -179,16 +179,22 @@ def main():
 
     if not a.no_roofline:
         # one more pass of the same workload with HIP events around every launch (on the launch stream)
+        import ctypes
+        rows_done = ctypes.c_ulonglong(0)
+        torch.cuda.synchronize()
+        capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         capi.lib.edgehip_prof_enable(1)
         one_pass(10 ** 6)
         torch.cuda.synchronize()
+        capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         prof = capi.prof_collect()
         capi.lib.edgehip_prof_enable(0)
         tot = sum(v[0] for v in prof.values())
         kern = {k: {'ms': round(v[0], 3), 'launches': v[1], 'avg_us': round(1e3 * v[0] / v[1], 3),
                     'share': round(v[0] / tot, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         dom = next(iter(kern))
-        Nn = n * B
+        # rows per launch that were really processed: graphs without active pairs are skipped by the kernels
+        Nn = rows_done.value / kern['layer']['launches'] if dom == 'layer' else n * B
         w = kernel_work(dom, Nn, kern[dom]['launches'])
         roof = None
         if w is not None:
@@ -204,6 +210,7 @@ def main():
                         'frac': ach / HBM_PEAK_GBPS, 'traffic': None}
             roof['traffic'], roof['traffic_source'] = pmc_traffic(dom)
             roof['avg_launch_us'] = kern[dom]['avg_us']
+            roof['rows_per_launch'] = Nn
             roof['algorithmic_bytes_per_launch'] = by
             roof['algorithmic_flops_per_launch'] = fl
         res['roofline'] = roof

@@ -280,13 +280,21 @@ __global__ __launch_bounds__(256) void k_time_embed(edgehip_gnn_params P, const 
 // node_in: h0 = silu(at*x_t + a0*x_0 + as[sel]) and per-tile column sums (layers.py:326-342)
 // one wave per node tile, lane = channel
 // --------------------------------------------------------------------------------------------
+// A graph with fewer than two active nodes has no active pair: none of its logits is ever read, and graphs
+// do not interact inside the network, so every per-node / per-graph kernel skips it (`idle` = kptr, or
+// null to compute everything, e.g. when the caller asks for the node states h_out).
+__device__ static inline bool eh_graph_idle(const int32_t* __restrict__ kptr, int g) {
+    return kptr != nullptr && kptr[g + 1] - kptr[g] < 2;
+}
+
 __global__ __launch_bounds__(256) void k_node_in(edgehip_layout L, int max_degree, const float* __restrict__ at,
                                                  const float* __restrict__ a0, const float* __restrict__ as,
                                                  const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
-                                                 const uint8_t* __restrict__ flags, float* __restrict__ h0,
-                                                 float* __restrict__ part) {
+                                                 const uint8_t* __restrict__ flags, const int32_t* __restrict__ idle,
+                                                 float* __restrict__ h0, float* __restrict__ part) {
     int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (tile >= L.num_tiles) return;
+    if (eh_graph_idle(idle, L.tile_graph[tile])) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
@@ -389,9 +397,10 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
                                                       const float* __restrict__ part, const float* __restrict__ te,
                                                       int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
                                                       int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
-                                                      float* __restrict__ cbias) {
+                                                      float* __restrict__ cbias, const int32_t* __restrict__ idle) {
     __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
     const int g = blockIdx.x, prt = blockIdx.y, tid = threadIdx.x;
+    if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
     const int t0 = L.tile_ptr[g], t1 = L.tile_ptr[g + 1];
     const int width = (l == 0) ? 64 : 256;
@@ -699,12 +708,13 @@ __global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __re
 #define EH_HEAVY_DEG 40
 #endif
 
-__global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, int32_t* __restrict__ counter,
+__global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, const int32_t* __restrict__ node_graph,
+                                                    const int32_t* __restrict__ idle, int32_t* __restrict__ counter,
                                                     int32_t* __restrict__ heavy_nodes, int32_t* __restrict__ heavy_slot) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Nn) return;
     int slot = -1;
-    if (deg[i] > EH_HEAVY_DEG) { slot = atomicAdd(counter, 1); heavy_nodes[slot] = i; }
+    if (deg[i] > EH_HEAVY_DEG && !eh_graph_idle(idle, node_graph[i])) { slot = atomicAdd(counter, 1); heavy_nodes[slot] = i; }
     heavy_slot[i] = slot;    // list order is arbitrary; every slot is computed independently of the others
 }
 
@@ -915,6 +925,7 @@ struct eh_layer_args {
     const float *w_ih, *w_hh, *b_ih, *b_hh;
     const float* cw0; const float* cbias;
     const int32_t* heavy_slot; const float* zheavy;   // rows walked by k_attn_heavy (slot >= 0)
+    const int32_t* idle;                               // kptr: tiles of graphs without active pairs exit (or null)
     float* hnew; float* part;
 };
 
@@ -936,6 +947,15 @@ extern "C" int edgehip_debug_read(unsigned long long* out_host, int reset) {
 #define EH_SUB_BEGIN() do { } while (0)
 #define EH_SUB_AT(k) do { } while (0)
 #endif
+
+// node rows the fused layer kernel actually processed (idle graphs excluded) since the last read
+__device__ unsigned long long eh_layer_rows;
+extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) {
+    if (!out_host) return EDGEHIP_ERR_ARG;
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(eh_layer_rows), sizeof(unsigned long long)) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+    if (reset) { unsigned long long z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(eh_layer_rows), &z, sizeof(z)); }
+    return EDGEHIP_OK;
+}
 
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
 #define EH_TSZ (32 * EH_TP)
@@ -963,6 +983,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     }
     const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
+    if (eh_graph_idle(a.idle, g)) return;
+    if (tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // executed work, for the roofline figure
     const int r = lane & 31, hh = lane >> 5;
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -1334,6 +1356,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     const int B = L->num_graphs, Nn = L->num_nodes, NT = L->num_tiles;
     if (B == 0 || Nn == 0) return EDGEHIP_OK;
     if ((int64_t)Nn * 256 > 0xFFFFFFFFll) return EDGEHIP_ERR_UNSUPPORTED;   // neighbour rows are addressed by 32-bit byte offsets
+    const int32_t* idle = h_out ? nullptr : kptr;        // h_out wants every node's state: no graph is skipped
     const int tile_blocks = (NT + 3) / 4;
     int hmax = 1;
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
@@ -1341,9 +1364,9 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
 
     EH_PROF(EH_K_TIME_EMBED, s, hipLaunchKernelGGL(k_time_embed, dim3(t_shared ? 1 : B), dim3(256), 0, s, *P, t_graph, w.te));
     EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_node_in, dim3(tile_blocks), dim3(256), 0, s, *L, P->max_degree, folded + fm.nin_at,
-                       folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, w.hA, w.part));
+                       folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, idle, w.hA, w.part));
     (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
-    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_heavy_list, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, deg, w.heavy_count, w.heavy_nodes,
+    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_heavy_list, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, deg, L->node_graph, idle, w.heavy_count, w.heavy_nodes,
                        w.heavy_slot));
     float* hcur = w.hA;
     float* hnext = w.hB;
@@ -1357,7 +1380,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         }
         EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, w.te, t_shared,
                            w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64, w.ctx + (size_t)(l & 1) * (B + 1) * 64,
-                           w.qbias, ldq, w.obias0, w.obias1, w.cbias));
+                           w.qbias, ldq, w.obias0, w.obias1, w.cbias, idle));
         if (l == P->num_layers) break;
         const int h = P->heads[l];
         eh_layer_args la = {};
@@ -1366,7 +1389,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.Ocat = folded + fm.layer[l].pOcat; la.obias0 = w.obias0; la.obias1 = w.obias1;
         la.w_ih = folded + fm.pWih; la.w_hh = folded + fm.pWhh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
-        la.heavy_slot = w.heavy_slot; la.zheavy = w.Z;
+        la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
         // qt of the heavy rows: gathered-row GEMM into the compact buffer w.Qt, then one block per heavy row
         {
             eh_gemm_desc d = {};

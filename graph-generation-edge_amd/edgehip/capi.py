@@ -123,6 +123,8 @@ def _load():
     lib.edgehip_prof_kernel_name.argtypes = [C.c_int32]
     lib.edgehip_prof_kernel_name.restype = C.c_char_p
     lib.edgehip_prof_num_kernels.restype = C.c_int32
+    lib.edgehip_prof_layer_rows.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    lib.edgehip_prof_layer_rows.restype = C.c_int
     return lib
 
 
@@ -138,7 +140,8 @@ def check(rc, what=''):
         raise EdgeHipError(f'{what}: {_ERR.get(rc, rc)} ({rc})')
 
 
-PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels')
+PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels',
+                'edgehip_prof_layer_rows')
 
 
 def prof_collect():

@@ -327,6 +327,9 @@ int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float* b4, const
 int edgehip_prof_enable(int on);
 int edgehip_prof_collect(double* ms_host, int64_t* launches_host, int32_t n);
 const char* edgehip_prof_kernel_name(int32_t id);
+/* node rows the fused layer kernel processed since the last reset (graphs without active pairs are skipped);
+ * synchronises.  bench.py prices the roofline with the work that was executed, not the batch size. */
+int edgehip_prof_layer_rows(unsigned long long* out_host, int reset);
 int32_t edgehip_prof_num_kernels(void);
 
 const char* edgehip_version(void);
