@@ -23,6 +23,7 @@ struct eh_fold_map {
     // the same matrices re-laid in MFMA fragment order (eh_pack_index): one 1-KiB coalesced load per
     // fragment instruction instead of 64 lines
     size_t pWih, pWhh, pCw0, pNo0, pNo2, pW4f, pFw2;
+    size_t te_table;                 // [T][MAX_LAYERS][64] per-layer time embeddings of every step t
     eh_fold_layer layer[EDGEHIP_MAX_LAYERS];
     size_t total;
 };
@@ -42,6 +43,7 @@ static eh_fold_map eh_make_fold_map(const edgehip_gnn_params* P) {
         m.layer[l].Vsum = take(64 * 64);
         m.layer[l].pMcat = take(H * 64); m.layer[l].pOcat = take(64 * (H + 64));
     }
+    m.te_table = take((size_t)P->num_steps * EDGEHIP_MAX_LAYERS * 64);
     m.total = o;
     return m;
 }
@@ -155,6 +157,8 @@ static void eh_pack(const float* W, int ldw, int col0, int N, int K, float* out,
     hipLaunchKernelGGL(k_pack_w, dim3((N * K / 4 + 255) / 256), dim3(256), 0, s, W, ldw, col0, N, K, out);
 }
 
+__global__ void k_time_embed(edgehip_gnn_params P, const int32_t* __restrict__ t_graph, float* __restrict__ te);
+
 extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, void* stream) {
     int rc = eh_check_params(P);
     if (rc != EDGEHIP_OK) return rc;
@@ -162,6 +166,8 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
     eh_fold_map m = eh_make_fold_map(P);
     hipStream_t s = eh_stream(stream);
     hipLaunchKernelGGL(k_fold_nin, dim3(1), dim3(64), 0, s, *P, folded + m.nin_at, folded + m.nin_a0, folded + m.nin_as);
+    // the time embedding depends on (t, layer) only: one table for all steps instead of a launch per step
+    hipLaunchKernelGGL(k_time_embed, dim3(P->num_steps), dim3(256), 0, s, *P, (const int32_t*)nullptr, folded + m.te_table);
     hipLaunchKernelGGL(k_fold_tail, dim3(128), dim3(128), 0, s, P->final_w0, P->node_out_w4, P->node_out_b4,
                        folded + m.W4f, folded + m.b4f);
     for (int l = 0; l < P->num_layers; ++l) {
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) void k_time_embed(edgehip_gnn_params P, const 
                                                     float* __restrict__ te) {
     __shared__ float pe[64], hid[256], tt[64];
     int g = blockIdx.x, tid = threadIdx.x;
-    int t = t_graph[g];
+    int t = t_graph ? t_graph[g] : g;            // null: block index = step (building the table of all steps)
     if (tid < 64) pe[tid] = P.pos_emb[(size_t)t * 64 + tid];
     __syncthreads();
     {
@@ -394,8 +400,8 @@ __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld
 // per-graph bias vectors of layer l, so that 4 x B blocks are in flight instead of B.
 #define EH_GU_PARTS 4
 __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, int l, eh_layer_ptrs lp,
-                                                      const float* __restrict__ part, const float* __restrict__ te,
-                                                      int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
+                                                      const float* __restrict__ part, const float* __restrict__ te /*[T][L][64]*/,
+                                                      const int32_t* __restrict__ t_graph, int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
                                                       int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
                                                       float* __restrict__ cbias, const int32_t* __restrict__ idle) {
     __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
     }
     if (tid < 64) {
         zero64[tid] = 0.f;
-        if (l < P.num_layers) tev[tid] = te[((size_t)(te_shared ? 0 : g) * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
+        if (l < P.num_layers) tev[tid] = te[((size_t)t_graph[te_shared ? 0 : g] * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
     }
     __syncthreads();
     if (l == 0) {
@@ -718,17 +724,6 @@ __global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __res
     heavy_slot[i] = slot;    // list order is arbitrary; every slot is computed independently of the others
 }
 
-// per-graph bias of the gathered heavy rows: qheavy[i][o] += qbias[graph(heavy_nodes[i])][o]
-__global__ __launch_bounds__(256) void k_heavy_qbias(edgehip_layout L, int H, const float* __restrict__ qbias, int ldq,
-                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
-                                                     float* __restrict__ qheavy) {
-    const int64_t total = (int64_t)(*counter) * H;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int i = (int)(e / H), o = (int)(e % H);
-        qheavy[e] += qbias[(size_t)L.node_graph[heavy_nodes[i]] * ldq + o];
-    }
-}
-
 // Walk one decoded neighbour list (ids in LDS, padded with filler ids to a whole step) for ONE target,
 // continuing the online-softmax state (m, l, acc).  Lane = (slot, head, c): channels 8c..8c+7 of one head;
 // HEADS < 8 runs 8/HEADS neighbours side by side (slots; merged by the caller with eh_merge_slots).
@@ -848,6 +843,7 @@ __device__ static inline void eh_merge_slots(f32x2 (&acc)[4], float& m, float& l
 template <int HEADS>
 __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
                                                     const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
+                                                    const float* __restrict__ qbias, int ldq,
                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
                                                     float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
@@ -873,8 +869,10 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
         f32x2 q[4], acc[4];
         float m = -1e30f, lsum = 0.f;
         {
+            // qt row of the gathered GEMM + the per-graph bias (time embedding / context terms)
             const f32x4* qp = reinterpret_cast<const f32x4*>(qheavy + (size_t)idx * H + head * 64 + c * 8);
-            const f32x4 q0 = qp[0], q1 = qp[1];
+            const f32x4* bp = reinterpret_cast<const f32x4*>(qbias + (size_t)g * ldq + head * 64 + c * 8);
+            const f32x4 q0 = qp[0] + bp[0], q1 = qp[1] + bp[1];
             q[0] = f32x2{q0[0], q0[1]}; q[1] = f32x2{q0[2], q0[3]}; q[2] = f32x2{q1[0], q1[1]}; q[3] = f32x2{q1[2], q1[3]};
 #pragma unroll
             for (int d = 0; d < 4; ++d) acc[d] = f32x2{0.f, 0.f};
@@ -1362,7 +1360,6 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    EH_PROF(EH_K_TIME_EMBED, s, hipLaunchKernelGGL(k_time_embed, dim3(t_shared ? 1 : B), dim3(256), 0, s, *P, t_graph, w.te));
     EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_node_in, dim3(tile_blocks), dim3(256), 0, s, *L, P->max_degree, folded + fm.nin_at,
                        folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, idle, w.hA, w.part));
     (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
@@ -1378,7 +1375,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             lp.Vbbar = folded + f.Vbbar; lp.bvbar = folded + f.bvbar; lp.Vsum = folded + f.Vsum;
             lp.skip_w = P->skip_w[l]; lp.skip_b = P->skip_b[l]; lp.H = P->heads[l] * 64;
         }
-        EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, w.te, t_shared,
+        EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, folded + fm.te_table, t_graph, t_shared,
                            w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64, w.ctx + (size_t)(l & 1) * (B + 1) * 64,
                            w.qbias, ldq, w.obias0, w.obias1, w.cbias, idle));
         if (l == P->num_layers) break;
@@ -1398,14 +1395,13 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             d.prof_id = EH_K_GEMM_QT;
             int rc = eh_launch_gemm(d, s);
             if (rc != EDGEHIP_OK) return rc;
-            hipLaunchKernelGGL(k_heavy_qbias, dim3(1024), dim3(256), 0, s, *L, h * 64, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Qt);
         }
         const int hb = Nn < 4096 ? Nn : 4096;
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
         }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
