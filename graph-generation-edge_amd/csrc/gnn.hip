@@ -477,239 +477,19 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
 }
 
 // --------------------------------------------------------------------------------------------
-// attention over the bit-matrix row of each target node (one wave per node).
-// lane = 8*group + chunk: chunk c owns channels 8c..8c+7; group = slot*HEADS + head.  HEADS=8: the
-// 8 groups are the 8 heads of ONE neighbour; HEADS<8: 8/HEADS neighbours are processed at once and
-// their online-softmax states merged at the end.  Neighbour ids are popped from the row words with
-// scalar bit ops (ascending j, like the reference's edge order).
+// Attention over the bit-matrix rows (TransformerConv message passing, layers.py:354).  A row's bits are
+// decoded into an ascending neighbour list (= the reference's edge order) and walked with an online
+// softmax; lane = 8*group + chunk: chunk c owns channels 8c..8c+7, group = slot*HEADS + head.  HEADS = 8:
+// the 8 groups are the 8 heads of ONE neighbour; HEADS < 8: 8/HEADS neighbours side by side (slots) whose
+// states are merged when the target ends.
+//
+// Degrees are skewed (polblogs: mean 27, max ~350).  Rows with at most EH_HEAVY_DEG neighbours are walked
+// inside the fused layer kernel (phase B: a wave's 8 targets as one flat stream).  Heavier rows are listed
+// once per step (k_heavy_list) and, per layer, get one WAVE each (k_attn_heavy), their qt coming from a
+// gathered-row GEMM; z goes to zheavy[slot] and the fused kernel copies it instead of walking the row.
 // --------------------------------------------------------------------------------------------
-// One target node (or a word range of its row).  Per 64-word chunk of the bit-matrix row:
-//   1. decode: every lane holds one word; popcount + wave prefix sum give each lane its place in an
-//      ascending neighbour-id list in LDS (vector ops - a scalar pop per neighbour cost ~25 SALU each);
-//   2. gather: rows of h are fetched ONCE per neighbour, 16 lanes x 16 B per row, RB rows per step, the
-//      next step's loads in flight while the current one is consumed, and staged in a small LDS ring
-//      (the head groups of a wave all need the same row: reading it back from LDS is a broadcast);
-//   3. online softmax over the step: scores (pass 1), then the weighted sum (pass 2), both from LDS.
-// q: this lane's 8 channels of qt for its head.  Returns the raw state (m, l, acc) so partial walks of
-// one row can be merged; eh_attend normalises.
 #define EH_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int HEADS, int SUBW, int RB>
-__device__ static inline void eh_attend_raw(const uint32_t* __restrict__ rowp, int w_begin, int w_end,
-                                            uint32_t first_word, int node0, const float* __restrict__ hsrc,
-                                            const float (&q)[8], int lane, float (&acc)[8], float& m, float& lsum,
-                                            int* __restrict__ ids, float* __restrict__ ring) {
-    constexpr int NSLOT = 8 / HEADS;
-    constexpr int UP = (RB + NSLOT - 1) / NSLOT;     // neighbours per lane and step
-    constexpr int NL = RB / 4;                       // 1-KiB load instructions per step
-    static_assert(RB % 4 == 0 && RB <= 8, "ring sized for at most 8 rows");
-    const int grp = lane >> 3, c = lane & 7;
-    const int slot = grp / HEADS;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) acc[d] = 0.f;
-    m = -INFINITY; lsum = 0.f;
-
-    auto issue = [&](int n, int total, f32x4 (&st)[NL]) {
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            int rr = n + k * 4 + (lane >> 4);
-            int id = ids[rr < total ? rr : total - 1];
-            st[k] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)id * 64 + (lane & 15) * 4);
-        }
-    };
-    auto step = [&](const f32x4 (&st)[NL], int n0, int total) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < NL; ++k)
-            *reinterpret_cast<f32x4*>(ring + (k * 4 + (lane >> 4)) * 64 + (lane & 15) * 4) = st[k];
-        EH_LDS_SYNC();
-        float sc[UP];
-        float mn = m;
-#pragma unroll
-        for (int u = 0; u < UP; ++u) {
-            const int rr = u * NSLOT + slot;
-            const bool valid = rr < RB && n0 + rr < total;
-            const float* xp = ring + (rr < RB ? rr : 0) * 64 + c * 8;
-            f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-            float t = 0.f;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) t += q[d] * x0[d] + q[4 + d] * x1[d];
-            t = eh_group8_sum(t);
-            sc[u] = valid ? t : -INFINITY;
-            mn = fmaxf(mn, sc[u]);
-        }
-        asm volatile("" ::: "memory");        // pass 2 re-reads the rows from LDS instead of keeping 8 of them in VGPRs
-        if (mn > -INFINITY) {                 // this slot has seen at least one neighbour
-            const float resc = __expf(m - mn);      // m = -inf before the first neighbour: exp(-inf) = 0
-            float ps = 0.f;
-#pragma unroll
-            for (int u = 0; u < UP; ++u) { sc[u] = __expf(sc[u] - mn); ps += sc[u]; }
-            lsum = lsum * resc + ps;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc[d] *= resc;
-#pragma unroll
-            for (int u = 0; u < UP; ++u) {
-                const int rr = u * NSLOT + slot;
-                const float* xp = ring + (rr < RB ? rr : 0) * 64 + c * 8;
-                f32x4 x0 = *reinterpret_cast<const f32x4*>(xp), x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) { acc[d] += sc[u] * x0[d]; acc[4 + d] += sc[u] * x1[d]; }
-            }
-            m = mn;
-        }
-        asm volatile("" ::: "memory");
-    };
-
-    for (int w0 = w_begin; w0 < w_end; w0 += 64) {
-        const uint32_t word = (w0 == w_begin) ? first_word : ((w0 + lane < w_end) ? rowp[w0 + lane] : 0u);
-        const unsigned long long nzmask = __ballot(word != 0u);
-        if (nzmask == 0ull) continue;
-#pragma unroll 1
-        for (int sb = 0; sb < 64; sb += SUBW) {
-            if (SUBW < 64 && ((nzmask >> sb) & ((1ull << (SUBW & 63)) - 1ull)) == 0ull) continue;
-            uint32_t w = (SUBW == 64 || (lane >= sb && lane < sb + SUBW)) ? word : 0u;
-            const int cnt = __popc(w);
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
-            }
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            int pos = incl - cnt;
-            const int jb = node0 + (w0 + lane) * 32;
-            while (w) { ids[pos++] = jb + __ffs((int)w) - 1; w &= w - 1; }
-            EH_LDS_SYNC();
-            // steps of RB neighbours, two register sets ping-pong
-            f32x4 sa[NL], sb2[NL];
-            const int nsteps = (total + RB - 1) / RB;
-            issue(0, total, sa);
-#pragma unroll 1
-            for (int g = 0; g < nsteps; g += 2) {
-                if (g + 1 < nsteps) issue((g + 1) * RB, total, sb2);
-                step(sa, g * RB, total);
-                if (g + 1 >= nsteps) break;
-                if (g + 2 < nsteps) issue((g + 2) * RB, total, sa);
-                step(sb2, (g + 1) * RB, total);
-            }
-            EH_LDS_SYNC();
-        }
-    }
-    if (NSLOT > 1) {
-#pragma unroll
-        for (int off = 8 * HEADS; off < 64; off <<= 1) {
-            float m2 = __shfl_xor(m, off), l2 = __shfl_xor(lsum, off);
-            float mn = fmaxf(m, m2);
-            float s1 = (m == -INFINITY) ? 0.f : __expf(m - mn);
-            float s2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
-            lsum = lsum * s1 + l2 * s2;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                float a2 = __shfl_xor(acc[d], off);
-                acc[d] = acc[d] * s1 + a2 * s2;
-            }
-            m = mn;
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// GRU cell (torch.nn.GRU(64,64), one step; layers.py:360): one wave per node tile, MFMA for the six
-// 64x64 products, gate math in the accumulator layout.
-// --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gru(edgehip_layout L, const float* __restrict__ w_ih,
-                                             const float* __restrict__ w_hh, const float* __restrict__ b_ih,
-                                             const float* __restrict__ b_hh, const float* __restrict__ xin,
-                                             const float* __restrict__ hprev, float* __restrict__ hnew) {
-    // weight fragments straight from L2 (each is used once per wave; staging them through LDS with two
-    // barriers per column tile measured 15 % slower here)
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (tile >= L.num_tiles) return;
-    const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
-    const int r = lane & 31, hh = lane >> 5;
-    const int64_t arow = row0 + (r < rows ? r : rows - 1);
-    eh_frag am, ah;
-    eh_load_frag(am, xin + arow * 64 + hh * 32);
-    eh_load_frag(ah, hprev + arow * 64 + hh * 32);
-#pragma unroll 1
-    for (int ct = 0; ct < 2; ++ct) {
-        f32x16 ar = eh_zero16(), az = eh_zero16(), ain = eh_zero16(), ahn = eh_zero16();
-        eh_frag bf;
-        const int wr = ct * 32 + r;
-        eh_load_frag(bf, w_ih + (size_t)(wr) * 64 + hh * 32);        eh_mma64(ar, am, bf);
-        eh_load_frag(bf, w_hh + (size_t)(wr) * 64 + hh * 32);        eh_mma64(ar, ah, bf);
-        eh_load_frag(bf, w_ih + (size_t)(64 + wr) * 64 + hh * 32);   eh_mma64(az, am, bf);
-        eh_load_frag(bf, w_hh + (size_t)(64 + wr) * 64 + hh * 32);   eh_mma64(az, ah, bf);
-        eh_load_frag(bf, w_ih + (size_t)(128 + wr) * 64 + hh * 32);  eh_mma64(ain, am, bf);
-        eh_load_frag(bf, w_hh + (size_t)(128 + wr) * 64 + hh * 32);  eh_mma64(ahn, ah, bf);
-        const int col = ct * 32 + r;
-        const float bir = b_ih[col] + b_hh[col], biz = b_ih[64 + col] + b_hh[64 + col];
-        const float bin = b_ih[128 + col], bhn = b_hh[128 + col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int rr = eh_crow(i, lane);
-            if (rr < rows) {
-                size_t o = (size_t)(row0 + rr) * 64 + col;
-                float rg = eh_sigmoid_fast(((ar[i] + bir)));
-                float zg = eh_sigmoid_fast(((az[i] + biz)));
-                float ng = eh_tanh_fast((ain[i] + bin) + rg * (ahn[i] + bhn));
-                float hp = hprev[o];
-                hnew[o] = (1.0f - zg) * ng + zg * hp;
-            }
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// context pre-activation: s_i = silu(W_c1[:, :64] h_i + cbias_g), per-tile column sums (layers.py:366-367)
-// --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ctx(edgehip_layout L, const float* __restrict__ w0 /*[256,128]*/,
-                                             const float* __restrict__ cbias, const float* __restrict__ h,
-                                             float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float wt[64 * EH_WPITCH];
-    const int lane = threadIdx.x & 63;
-    int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool live = tile < L.num_tiles;
-    if (!live) tile = L.num_tiles - 1;
-    const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
-    const int r = lane & 31, hh = lane >> 5;
-    const int64_t arow = row0 + (r < rows ? r : rows - 1);
-    eh_frag a;
-    eh_load_frag(a, h + arow * 64 + hh * 32);
-#pragma unroll 1
-    for (int np = 0; np < 4; ++np) {
-        __syncthreads();
-        eh_stage_w<64>(wt, w0, 128, np * 64, 0);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x16 acc = eh_zero16();
-            eh_frag bf;
-            eh_load_frag_lds(bf, wt, j * 32 + r, hh);
-            eh_mma64(acc, a, bf);
-            const int col = np * 64 + j * 32 + r;
-            const float cb = cbias[(size_t)g * 256 + col];
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int rr = eh_crow(i, lane);
-                float v = eh_silu_fast(acc[i] + cb);
-                s += (rr < rows) ? v : 0.f;
-            }
-            s += __shfl_xor(s, 32);
-            if (live && lane < 32) part[(size_t)tile * 256 + col] = s;
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// Heavy rows.  Degrees are skewed (polblogs: mean 27, max ~350): a hub walked by one wave is a serial
-// chain that idles the rest of its tile.  Nodes with more than EH_HEAVY_DEG neighbours are listed once
-// per step (k_heavy_list) and, per layer, get a whole block (k_attn_heavy): qt by a 64 x 64h GEMV,
-// the bit row split into four word ranges (one per wave), partial softmax states merged through LDS,
-// z written to zheavy[slot].  The fused layer kernel copies that z instead of walking the row.
-// --------------------------------------------------------------------------------------------
 #ifndef EH_HEAVY_DEG
 #define EH_HEAVY_DEG 40
 #endif
@@ -962,7 +742,10 @@ template <int HEADS>
 __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a) {
     constexpr int H = HEADS * 64, QP = H + 4;
     constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG];
+#ifndef EH_EXP_LDS_PAD
+#define EH_EXP_LDS_PAD 0          // occupancy experiments only
+#endif
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + EH_EXP_LDS_PAD];
     float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
     float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
     float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
