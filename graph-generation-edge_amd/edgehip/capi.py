@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EDGEHIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libedgehip.so')
 
 MAX_LAYERS = 8
+NSTAT = 10
 TILE_ROWS = 32
 PAIR_TILE = 32
 
@@ -75,6 +76,8 @@ EXPORTS = {
     'edgehip_sample_step': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp,
                             C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
     'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],
+    'edgehip_graph_stats': [C.POINTER(Layout), vp, vp, vp, vp],
+    'edgehip_edge_overlap': [C.POINTER(Layout), vp, vp, vp, vp],
     # training ops (csrc/train.hip)
     'edgehip_train_embed_fwd': [C.POINTER(Layout), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],
     'edgehip_train_embed_bwd': [C.POINTER(Layout), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],

@@ -319,6 +319,21 @@ int edgehip_edge_ce_fwd(const float* e2, const float* W4, const float* b4, const
 int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float* b4, const uint8_t* tgt, const int32_t* pair_graph,
                         const float* gkl, int64_t A, float* de2, float* dW4, float* db4, void* stream);
 
+/* ---- statistics of the sampled graphs (next row after the path) ------------------------
+ * replaces: the degree / triangle / assortativity part of compute_graph_statistics,
+ *           eval_utils/graph_statistics.py:9-123,202-230,249-285 (consumer datasets/evaluator.py:27-37)
+ * out [B][EDGEHIP_NSTAT] int64, exact integer sums per graph:
+ *   0 edges E; 1 wedges sum d(d-1)/2; 2 claws sum d(d-1)(d-2)/6; 3 sum over edges {i,j} of |N(i) & N(j)|
+ *   (= 3 x triangles); 4 sum_edges d_i d_j; 5 sum_edges (d_i + d_j); 6 sum_edges (d_i^2 + d_j^2);
+ *   7 d_max; 8 d_min; 9 sum d.   deg: edgehip_degree_from_adj of the same state. */
+#define EDGEHIP_NSTAT 10
+int edgehip_graph_stats(const edgehip_layout* L, const uint32_t* adj, const int32_t* deg, int64_t* out, void* stream);
+
+/* replaces: edge_overlap, eval_utils/graph_statistics.py:287-299.  out[B] = popcount(A & B) per graph
+ * (= 2 x shared edges) for two states of the same layout. */
+int edgehip_edge_overlap(const edgehip_layout* L, const uint32_t* adj_a, const uint32_t* adj_b, int64_t* out,
+                         void* stream);
+
 /* ---- measurement hooks (no counterpart in the reference; used by bench.py's roofline leg) -------
  * When enabled, every kernel launch of the path is bracketed by HIP events on its launch stream.
  * collect() synchronises on those events and returns, per kernel class, the summed device time (ms)

@@ -1,0 +1,82 @@
+"""GPU: graph statistics from the bit matrix against networkx / numpy on the same graphs.
+Counts are integers and must match exactly; assortativity and clustering are fp64 formulas of those
+integers (1e-9)."""
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+
+import cases
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _nx(g):
+    G = nx.Graph()
+    G.add_nodes_from(range(g['n']))
+    G.add_edges_from(np.asarray(g['edges']).tolist())
+    return G
+
+
+def _check(graphs):
+    import edgehip
+    b = H.graph_batch(graphs)
+    st = edgehip.graph_statistics(b)
+    for k, g in enumerate(graphs):
+        G = _nx(g)
+        d = np.array([G.degree(i) for i in range(g['n'])], dtype=np.int64)
+        assert st['num_edges'][k] == G.number_of_edges()
+        assert st['d_max'][k] == (d.max() if len(d) else 0) and st['d_min'][k] == (d.min() if len(d) else 0)
+        assert abs(st['d'][k] - d.mean()) < 1e-12
+        assert st['wedge_count'][k] == int((d * (d - 1) // 2).sum())
+        assert st['claw_count'][k] == int((d * (d - 1) * (d - 2) // 6).sum())
+        tri = sum(nx.triangles(G).values()) // 3
+        assert st['triangle_count'][k] == tri
+        if st['wedge_count'][k] > 0:
+            assert abs(st['clustering_coefficient'][k] - 3.0 * tri / st['wedge_count'][k]) < 1e-12
+            assert abs(st['clustering_coefficient'][k] - nx.transitivity(G)) < 1e-9
+        if G.number_of_edges() > 1 and d[d > 0].min() != d.max():
+            assert abs(st['assortativity'][k] - nx.degree_assortativity_coefficient(G)) < 1e-9
+
+
+def test_statistics_small_and_ragged():
+    graphs = cases.ragged_graphs(6)
+    graphs.append(dict(n=1, edges=np.zeros((0, 2), dtype=np.int64)))
+    graphs.append(dict(n=70, edges=np.stack(np.triu_indices(70, 1), 1)))          # complete graph, 3 words per row
+    _check(graphs)
+
+
+def test_statistics_polblogs_and_cora_shapes_and_overlap():
+    import edgehip
+    from edgehip import synth
+    gs = [dict(n=n, edges=e) for n, e in (synth.polblogs_like(0), synth.cora_like(0))]
+    _check(gs)
+    b = H.graph_batch(gs)
+    other = b.new_adj()
+    half = [g['edges'][::2] for g in gs]
+    off = np.cumsum([0] + [g['n'] for g in gs])
+    b.set_edges(other, np.concatenate([h + off[k] for k, h in enumerate(half)]))
+    ov = edgehip.edge_overlap(b, b.adj, other)
+    assert ov.tolist() == [len(h) for h in half]
+
+
+def test_statistics_of_a_sampled_batch():
+    """End of the pipeline: sample -> statistics, no host-side graph objects in between."""
+    import edgehip
+    from edgehip import synth
+    from oracle import edge_oracle as orc
+    n, e = synth.polblogs_like(0)
+    d = synth.degrees(n, e)
+    sampler = edgehip.EmpiricalEmptyGraphGenerator([(n, e)], degree=True, device='cuda')
+    model = H.build_model(orc.random_tgnn_params(3), 64, int(d.max()), sampler)
+    out = model.sample(3, seed=5)
+    st = edgehip.graph_statistics(out)
+    sl = out._slice_dict['edge_index'].cpu().numpy()
+    ei = out.edge_index.cpu().numpy()
+    for k in range(3):
+        G = nx.Graph()
+        G.add_nodes_from(range(n))
+        G.add_edges_from((ei[:, sl[k]:sl[k + 1]] - k * n).T.tolist())
+        assert st['num_edges'][k] == G.number_of_edges()
+        assert st['triangle_count'][k] == sum(nx.triangles(G).values()) // 3
