@@ -336,12 +336,6 @@ __device__ static inline float eh_dpp_f(float v, const int ctrl_sel) {
     else t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true);
     return __builtin_bit_cast(float, t);
 }
-__device__ static inline float eh_group8_sum(float v) {
-    v += eh_dpp_f(v, 0);
-    v += eh_dpp_f(v, 1);
-    v += eh_dpp_f(v, 2);
-    return v;
-}
 
 // Block-cooperative GEMV for the per-graph vectors: y[o] = bias[o] + W1[o,:K1] . x1 (+ W2[o,:64] . x2).
 // 16 lanes per output row, one float4 per lane and 64-wide chunk: every wave-level load covers four
@@ -491,7 +485,7 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
 #define EH_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 #ifndef EH_HEAVY_DEG
-#define EH_HEAVY_DEG 40
+#define EH_HEAVY_DEG 48         // multiple of every eh_walk_cfg<h>::UN (lists are padded to whole steps)
 #endif
 
 __global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, const int32_t* __restrict__ node_graph,
@@ -504,46 +498,71 @@ __global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __res
     heavy_slot[i] = slot;    // list order is arbitrary; every slot is computed independently of the others
 }
 
-// Walk one decoded neighbour list (ids in LDS, padded with filler ids to a whole step) for ONE target,
-// continuing the online-softmax state (m, l, acc).  Lane = (slot, head, c): channels 8c..8c+7 of one head;
-// HEADS < 8 runs 8/HEADS neighbours side by side (slots; merged by the caller with eh_merge_slots).
+// Walk one decoded neighbour list (row byte offsets in LDS, padded with filler entries to a whole step) for
+// ONE target, continuing the online-softmax state (m, l, acc).
+// Lane = (slot, head, c): EH_CPL consecutive channels of one head, so 64/EH_CPL lanes share a (slot, head)
+// group and EH_CPL/HEADS neighbours run side by side (slots; merged with eh_merge_slots when the target
+// ends).  EH_CPL = 8 is the measured optimum on polblogs: 16 halves the per-visit reduction / softmax
+// overhead on paper but lengthens the dependent FMA chains, doubles the slot merges and costs occupancy
+// (k_attn_heavy 98 -> 154 VGPRs): 14-25 % slower end to end.
 // U rounds per step: scores of the step first, one rescale, then the weighted sum; the rows of the next
 // step are in flight while the current one is consumed (two register sets).
+#ifndef EH_CPL
+#define EH_CPL 8
+#endif
+#define EH_LG (64 / EH_CPL)          // lanes per (slot, head) group
 template <int HEADS>
 struct eh_walk_cfg {
-    static constexpr int NSLOT = 8 / HEADS;
-    static constexpr int U = (HEADS == 8) ? 4 : (HEADS == 4 ? 2 : 1);
+    static constexpr int NSLOT = EH_CPL / HEADS;
+    static constexpr int U = (NSLOT >= 4) ? 1 : 4 / NSLOT;
     static constexpr int UN = U * NSLOT;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// one neighbour row chunk of a lane: channels 8c..8c+7 as four float pairs
-struct eh_x8 { f32x2 p[4]; };
+// one neighbour row chunk of a lane: its EH_CPL channels as float pairs
+struct eh_xr { f32x2 p[EH_CPL / 2]; };
+
+__device__ static inline void eh_load_cpl(f32x2 (&v)[EH_CPL / 2], const float* __restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < EH_CPL / 4; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * i);
+        v[2 * i] = f32x2{a[0], a[1]}; v[2 * i + 1] = f32x2{a[2], a[3]};
+    }
+}
+__device__ static inline void eh_store_cpl_scaled(float* __restrict__ p, const f32x2 (&v)[EH_CPL / 2], float sc) {
+#pragma unroll
+    for (int i = 0; i < EH_CPL / 4; ++i)
+        *reinterpret_cast<f32x4*>(p + 4 * i) = f32x4{v[2 * i][0] * sc, v[2 * i][1] * sc, v[2 * i + 1][0] * sc, v[2 * i + 1][1] * sc};
+}
 
 // Lists hold BYTE offsets of the neighbour rows (id * 256): the gather is `base + offset` with a 32-bit
 // offset (scalar base, no 64-bit address arithmetic per visit).
-__device__ static inline void eh_gather8(eh_x8& x, const float* __restrict__ hsrc, uint32_t row_off, int c) {
-    const f32x4* xp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * 32u));
-    const f32x4 a = xp[0], b = xp[1];
-    x.p[0] = f32x2{a[0], a[1]}; x.p[1] = f32x2{a[2], a[3]}; x.p[2] = f32x2{b[0], b[1]}; x.p[3] = f32x2{b[2], b[3]};
+__device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc, uint32_t row_off, int c) {
+    eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u))));
+}
+
+__device__ static inline float eh_group_sum(float v) {          // over the EH_LG lanes of a group
+    v += eh_dpp_f(v, 0);
+    if (EH_LG >= 4) v += eh_dpp_f(v, 1);
+    if (EH_LG >= 8) v += eh_dpp_f(v, 2);
+    return v;
 }
 
 // One step of the online softmax over U rounds (x[u] = this lane's slot's neighbour of round u).
 // nvalid: real visits left in the list at this step (>= UN: no masking needed).
 template <int HEADS>
-__device__ static inline void eh_walk_step(const f32x2 (&q)[4], const eh_x8 (&x)[eh_walk_cfg<HEADS>::U], int nvalid, int slot,
-                                           f32x2 (&acc)[4], float& m, float& lsum) {
+__device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const eh_xr (&x)[eh_walk_cfg<HEADS>::U], int nvalid,
+                                           int slot, f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
     float sc[U];
     float mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         f32x2 t2 = q[0] * x[u].p[0];
-        t2 = __builtin_elementwise_fma(q[1], x[u].p[1], t2);
-        t2 = __builtin_elementwise_fma(q[2], x[u].p[2], t2);
-        t2 = __builtin_elementwise_fma(q[3], x[u].p[3], t2);
-        sc[u] = eh_group8_sum(t2[0] + t2[1]);
+#pragma unroll
+        for (int d = 1; d < EH_CPL / 2; ++d) t2 = __builtin_elementwise_fma(q[d], x[u].p[d], t2);
+        sc[u] = eh_group_sum(t2[0] + t2[1]);
     }
     if (nvalid < UN) {                       // wave-uniform: only the last step of a list has filler visits
 #pragma unroll
@@ -558,29 +577,30 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[4], const eh_x8 (&x)
     lsum = lsum * resc + ps;
     const f32x2 r2 = f32x2{resc, resc};
 #pragma unroll
-    for (int d = 0; d < 4; ++d) acc[d] *= r2;
+    for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const f32x2 p2 = f32x2{sc[u], sc[u]};
 #pragma unroll
-        for (int d = 0; d < 4; ++d) acc[d] = __builtin_elementwise_fma(p2, x[u].p[d], acc[d]);
+        for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = __builtin_elementwise_fma(p2, x[u].p[d], acc[d]);
     }
     m = mn;
 }
 
 template <int HEADS>
 __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
-                                           const f32x2 (&q)[4], int lane, f32x2 (&acc)[4], float& m, float& lsum) {
+                                           const f32x2 (&q)[EH_CPL / 2], int lane, f32x2 (&acc)[EH_CPL / 2], float& m,
+                                           float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
-    const int grp = lane >> 3, c = lane & 7;
+    const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS;
     const int nsteps = (nvis + UN - 1) / UN;
     if (nsteps == 0) return;
-    auto fetch = [&](int gs, eh_x8 (&x)[U]) {
+    auto fetch = [&](int gs, eh_xr (&x)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) eh_gather8(x[u], hsrc, list[(gs * U + u) * NSLOT + slot], c);
+        for (int u = 0; u < U; ++u) eh_gather(x[u], hsrc, list[(gs * U + u) * NSLOT + slot], c);
     };
-    eh_x8 xa[U], xb[U];
+    eh_xr xa[U], xb[U];
     const int lastg = nsteps - 1;
     // sched_barrier: the scheduler otherwise sinks the prefetch loads next to their first use (the next
     // compute), which turns the pipeline into load -> wait -> compute
@@ -599,17 +619,17 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
     }
 }
 
-// merge the online-softmax states of the 8/HEADS slots (all lanes end with the merged state)
+// merge the online-softmax states of the slots (all lanes end with the merged state)
 template <int HEADS>
-__device__ static inline void eh_merge_slots(f32x2 (&acc)[4], float& m, float& lsum) {
+__device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
 #pragma unroll
-    for (int o = 8 * HEADS; o < 64; o <<= 1) {
+    for (int o = EH_LG * HEADS; o < 64; o <<= 1) {
         const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(lsum, o);
         const float mm = fmaxf(m, m2);
         const float s1 = __expf(m - mm), s2 = __expf(m2 - mm);
         lsum = lsum * s1 + l2 * s2;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < EH_CPL / 2; ++d) {
             const float a0 = __shfl_xor(acc[d][0], o), a1 = __shfl_xor(acc[d][1], o);
             acc[d][0] = acc[d][0] * s1 + a0 * s2;
             acc[d][1] = acc[d][1] * s1 + a1 * s2;
@@ -628,12 +648,12 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
                                                     float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
-    __shared__ uint32_t lists[4][2048 + 8];        // a 64-word chunk holds at most 2048 neighbours (+ step padding)
+    __shared__ uint32_t lists[4][2048 + 16];       // a 64-word chunk holds at most 2048 neighbours (+ step padding)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nheavy = *counter;
     uint32_t* list = lists[wave];
-    const int grp = lane >> 3, c = lane & 7;
+    const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS, head = grp % HEADS;
     // XCD affinity: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the contiguous slice
     // [x*nheavy/8, (x+1)*nheavy/8) of the list, which is roughly in node order, so an XCD touches the h rows
@@ -646,16 +666,15 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
         const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
-        f32x2 q[4], acc[4];
+        f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
         float m = -1e30f, lsum = 0.f;
         {
             // qt row of the gathered GEMM + the per-graph bias (time embedding / context terms)
-            const f32x4* qp = reinterpret_cast<const f32x4*>(qheavy + (size_t)idx * H + head * 64 + c * 8);
-            const f32x4* bp = reinterpret_cast<const f32x4*>(qbias + (size_t)g * ldq + head * 64 + c * 8);
-            const f32x4 q0 = qp[0] + bp[0], q1 = qp[1] + bp[1];
-            q[0] = f32x2{q0[0], q0[1]}; q[1] = f32x2{q0[2], q0[3]}; q[2] = f32x2{q1[0], q1[1]}; q[3] = f32x2{q1[2], q1[3]};
+            f32x2 qb[EH_CPL / 2];
+            eh_load_cpl(q, qheavy + (size_t)idx * H + head * 64 + c * EH_CPL);
+            eh_load_cpl(qb, qbias + (size_t)g * ldq + head * 64 + c * EH_CPL);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) acc[d] = f32x2{0.f, 0.f};
+            for (int d = 0; d < EH_CPL / 2; ++d) { q[d] += qb[d]; acc[d] = f32x2{0.f, 0.f}; }
         }
         for (int w0 = 0; w0 < stride; w0 += 64) {
             uint32_t w = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
@@ -677,12 +696,7 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
             EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
         }
         eh_merge_slots<HEADS>(acc, m, lsum);
-        if (slot == 0) {
-            const float inv = 1.0f / (lsum + 1e-16f);
-            f32x4* zp = reinterpret_cast<f32x4*>(zheavy + (size_t)idx * H + head * 64 + c * 8);
-            zp[0] = f32x4{acc[0][0] * inv, acc[0][1] * inv, acc[1][0] * inv, acc[1][1] * inv};
-            zp[1] = f32x4{acc[2][0] * inv, acc[2][1] * inv, acc[3][0] * inv, acc[3][1] * inv};
-        }
+        if (slot == 0) eh_store_cpl_scaled(zheavy + (size_t)idx * H + head * 64 + c * EH_CPL, acc, 1.0f / (lsum + 1e-16f));
     }
 }
 
@@ -822,12 +836,12 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
     // neighbours side by side (slots) and merges their softmax states when the target ends.
     {
-        constexpr int NSLOT = 8 / HEADS;
-        constexpr int U = (HEADS == 8) ? 4 : (HEADS == 4 ? 2 : 1);     // rounds per step
-        constexpr int UN = U * NSLOT;                                  // visits per step (divides EH_HEAVY_DEG)
+        constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;   // slots, rounds per step
+        constexpr int UN = eh_walk_cfg<HEADS>::UN;                     // visits per step (divides EH_HEAVY_DEG)
         static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
-        const int grp = lane >> 3, c = lane & 7;
-        const int slot = grp / HEADS, head = grp % HEADS;
+        const int wgrp = lane / EH_LG, wc = lane % EH_LG;              // walk layout: (slot, head) group, channel chunk
+        const int slot = wgrp / HEADS, head = wgrp % HEADS;
+        const int grp = lane >> 3, c = lane & 7;                       // copy layout of (d): target, 8-channel chunk
         uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (8 * EH_HEAVY_DEG);
         EH_SUB_BEGIN();
         // (b) decode the rows into ascending neighbour-id lists in LDS.  First 64 words of all 8 rows
@@ -894,16 +908,16 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         EH_SUB_AT(8);
         // (c) the flat walk
         {
-            f32x2 q[4], acc[4];
+            f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
             float mrun = -1e30f, lrun = 0.f;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
+            for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
             int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
-            auto fetch = [&](int gs, eh_x8 (&x)[U]) {
+            auto fetch = [&](int gs, eh_xr (&x)[U]) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) eh_gather8(x[u], a.hprev, flat[(gs * U + u) * NSLOT + slot], c);
+                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, flat[(gs * U + u) * NSLOT + slot], wc);
             };
-            auto compute = [&](const eh_x8 (&x)[U]) {
+            auto compute = [&](const eh_xr (&x)[U]) {
                 if (st == nst) {                         // next target with work
                     do {
                         ++k;
@@ -911,27 +925,21 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                         nst = (dk + UN - 1) / UN;
                     } while (nst == 0);
                     st = 0;
-                    const float* qrow = qz + (k * 4 + wave) * QP + head * 64 + c * 8;
-                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qrow), q1 = *reinterpret_cast<const f32x4*>(qrow + 4);
-                    q[0] = f32x2{q0[0], q0[1]}; q[1] = f32x2{q0[2], q0[3]}; q[2] = f32x2{q1[0], q1[1]}; q[3] = f32x2{q1[2], q1[3]};
+                    eh_load_cpl(q, qz + (k * 4 + wave) * QP + head * 64 + wc * EH_CPL);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) acc[d] = f32x2{0.f, 0.f};
+                    for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
                     mrun = -1e30f; lrun = 0.f;            // finite floor: exp(-1e30 - x) = 0 and never inf - inf
                 }
                 eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, lrun);
                 ++st;
                 if (st == nst) {                         // target finished: merge the slots, write z over its qt row
                     eh_merge_slots<HEADS>(acc, mrun, lrun);
-                    if (slot == 0) {
-                        const float inv = 1.0f / (lrun + 1e-16f);
-                        float* zrow = qz + (k * 4 + wave) * QP + head * 64 + c * 8;
-                        *reinterpret_cast<f32x4*>(zrow) = f32x4{acc[0][0] * inv, acc[0][1] * inv, acc[1][0] * inv, acc[1][1] * inv};
-                        *reinterpret_cast<f32x4*>(zrow + 4) = f32x4{acc[2][0] * inv, acc[2][1] * inv, acc[3][0] * inv, acc[3][1] * inv};
-                    }
+                    if (slot == 0)
+                        eh_store_cpl_scaled(qz + (k * 4 + wave) * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
                 }
             };
             if (total_steps > 0) {
-                eh_x8 xa[U], xb[U];
+                eh_xr xa[U], xb[U];
                 const int lastg = total_steps - 1;
                 fetch(0, xa);
 #pragma unroll 1
