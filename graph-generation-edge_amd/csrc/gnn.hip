@@ -198,6 +198,8 @@ struct eh_ws {
     float *hA, *hB, *Qt, *Z, *Mb, *part, *te, *ctx, *qbias, *obias0, *obias1, *cbias, *Xact, *U1, *U2;
     // step-level scratch
     int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *deg2, *heavy_nodes, *heavy_slot, *heavy_count;
+    int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
+    float* cwgt;
     int64_t* aptr;
     uint8_t* flags;
     float *node_repr, *tile_partial;
@@ -228,6 +230,8 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.deg = (int32_t*)take(NnP * 4); w.deg2 = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
     w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4); w.heavy_count = (int32_t*)take(256);
+    w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
+    w.ccount = (int32_t*)take((B + 1) * 4);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
     w.tptr = (int32_t*)take((B + 2) * 4); w.t_graph = (int32_t*)take((B + 1) * 4);
     w.aptr = (int64_t*)take((B + 2) * 8);
@@ -286,6 +290,67 @@ __global__ __launch_bounds__(256) void k_time_embed(edgehip_gnn_params P, const 
 // node_in: h0 = silu(at*x_t + a0*x_0 + as[sel]) and per-tile column sums (layers.py:326-342)
 // one wave per node tile, lane = channel
 // --------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// Live rows.  An ISOLATED node's state through all layers is a function of (d0, active flag) and of
+// per-graph vectors only (no neighbours: conv = skip + biases), so the isolated nodes of a graph that
+// share (d0, flag) are bit-identical copies of each other.  Per step and graph, k_compact keeps the
+// non-isolated nodes plus ONE representative per (d0, flag) class (the lowest node id), in ascending node
+// order, with a weight = class size that the context means multiply in.  The per-node kernels then run on
+// ceil(live/32) tiles instead of ceil(n/32): in the sparse half of the trajectory (t > T/2) most nodes are
+// isolated.  rep_of[i] = the row that holds node i's state.  dedupe = 0 keeps every node (h_out requested).
+// --------------------------------------------------------------------------------------------
+#define EH_CKEYS 4096          // (d0, flag) keys with a table slot; larger d0 -> the node stays its own row
+__global__ __launch_bounds__(256) void k_compact(edgehip_layout L, const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
+                                                 const uint8_t* __restrict__ flags, const int32_t* __restrict__ idle, int dedupe,
+                                                 int32_t* __restrict__ crow, float* __restrict__ cwgt,
+                                                 int32_t* __restrict__ rep_of, int32_t* __restrict__ ccount) {
+    __shared__ int rep[EH_CKEYS], cnt[EH_CKEYS];
+    __shared__ int wave_cnt[4];
+    __shared__ int running;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int node0 = L.node_ptr[g], n = L.node_ptr[g + 1] - node0;
+    if (idle != nullptr && idle[g + 1] - idle[g] < 2) {
+        if (tid == 0) ccount[g] = 0;
+        return;
+    }
+    for (int k = tid; k < EH_CKEYS; k += 256) { rep[k] = 0x7fffffff; cnt[k] = 0; }
+    if (tid == 0) running = 0;
+    __syncthreads();
+    if (dedupe) {
+        for (int li = tid; li < n; li += 256) {
+            const int i = node0 + li;
+            const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
+            if (deg[i] == 0 && key >= 0 && key < EH_CKEYS) { atomicMin(&rep[key], li); atomicAdd(&cnt[key], 1); }
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int li = base + tid;
+        int live = 0, holder = 0;
+        float wgt = 1.0f;
+        if (li < n) {
+            const int i = node0 + li;
+            const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
+            const bool cls = dedupe && deg[i] == 0 && key >= 0 && key < EH_CKEYS;
+            live = !cls || rep[key] == li;
+            holder = cls ? node0 + rep[key] : i;
+            wgt = cls ? (float)cnt[key] : 1.0f;
+            rep_of[i] = holder;
+        }
+        const unsigned long long m = __ballot(live);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+        if (live) { crow[node0 + off + before] = node0 + li; cwgt[node0 + off + before] = wgt; }
+        __syncthreads();
+        if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) ccount[g] = running;
+}
+
 // A graph with fewer than two active nodes has no active pair: none of its logits is ever read, and graphs
 // do not interact inside the network, so every per-node / per-graph kernel skips it (`idle` = kptr, or
 // null to compute everything, e.g. when the caller asks for the node states h_out).
@@ -397,12 +462,14 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
                                                       const float* __restrict__ part, const float* __restrict__ te /*[T][L][64]*/,
                                                       const int32_t* __restrict__ t_graph, int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
                                                       int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
-                                                      float* __restrict__ cbias, const int32_t* __restrict__ idle) {
+                                                      float* __restrict__ cbias, const int32_t* __restrict__ idle,
+                                                      const int32_t* __restrict__ ccount) {
     __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
     const int g = blockIdx.x, prt = blockIdx.y, tid = threadIdx.x;
     if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
-    const int t0 = L.tile_ptr[g], t1 = L.tile_ptr[g + 1];
+    // l == 0: sums of k_node_in over all (static) tiles; l >= 1: weighted sums of the LIVE tiles of k_layer
+    const int t0 = L.tile_ptr[g], t1 = (l == 0) ? L.tile_ptr[g + 1] : t0 + (ccount[g] + 31) / 32;
     const int width = (l == 0) ? 64 : 256;
     if (tid < width) {
         // eight independent partial sums: the tile loads of a trip are all in flight together (a plain
@@ -718,6 +785,7 @@ struct eh_layer_args {
     const float* cw0; const float* cbias;
     const int32_t* heavy_slot; const float* zheavy;   // rows walked by k_attn_heavy (slot >= 0)
     const int32_t* idle;                               // kptr: tiles of graphs without active pairs exit (or null)
+    const int32_t* crow; const float* cwgt; const int32_t* ccount;   // live rows (k_compact): node ids, weights, count per graph
     float* hnew; float* part;
 };
 
@@ -759,7 +827,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #ifndef EH_EXP_LDS_PAD
 #define EH_EXP_LDS_PAD 0          // occupancy experiments only
 #endif
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + EH_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 64 + EH_EXP_LDS_PAD];
     float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
     float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
     float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
@@ -767,6 +835,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     float* ht = lds + 5 * EH_TSZ;       // [32][68]   h'
     float* hp = lds + R1;               // [32][68]   h (layer input / GRU hidden)
     int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [4 waves][8 targets][EH_HEAVY_DEG] neighbour ids
+    int* nl = idl + 4 * 8 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
+    float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so XCD x gets the
@@ -777,10 +847,16 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
         tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     }
-    const int row0 = L.tile_row0[tile], rows = L.tile_rows[tile], g = L.tile_graph[tile];
+    const int g = L.tile_graph[tile];
     if (eh_graph_idle(a.idle, g)) return;
+    // the tile's rows are the LIVE rows 32j .. 32j+31 of its graph (k_compact), not 32 consecutive nodes
+    const int cbase = L.node_ptr[g] + 32 * (tile - L.tile_ptr[g]);
+    const int rows = min(32, L.node_ptr[g] + a.ccount[g] - cbase);
+    if (rows <= 0) return;
     if (tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // executed work, for the roofline figure
     const int r = lane & 31, hh = lane >> 5;
+    const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
+    if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -791,20 +867,21 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     const int stride = L.adj_stride[g];
     const uint32_t* gadj = a.adj + L.adj_ptr[g];
     const bool mine8 = lane < 8 && lane * 4 + wave < rows;
-    const int hs8 = mine8 ? a.heavy_slot[row0 + lane * 4 + wave] : -1;
-    const int dg8 = mine8 ? a.deg[row0 + lane * 4 + wave] : 0;
+    const int nid8 = __shfl(mynid, (lane & 7) * 4 + wave);                // lane k < 8: node id of target k
+    const int hs8 = mine8 ? a.heavy_slot[nid8] : -1;
+    const int dg8 = mine8 ? a.deg[nid8] : 0;
     uint32_t fw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
-        fw[k] = (need && lane < stride) ? gadj[(int64_t)(row0 + k * 4 + wave - node0) * stride + lane] : 0u;
+        fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid8, k) - node0) * stride + lane] : 0u;
     }
 
     // ---- phase 0: h tile -> LDS (full-line loads)
 #pragma unroll
     for (int i = tid; i < 512; i += 256) {
         int row = i >> 4, c4 = i & 15;
-        int src = row0 + (row < rows ? row : rows - 1);
+        int src = __shfl(mynid, row);
         *reinterpret_cast<f32x4*>(hp + row * EH_TP + c4 * 4) =
             *reinterpret_cast<const f32x4*>(a.hprev + (size_t)src * 64 + c4 * 4);
     }
@@ -875,7 +952,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 if (stride > 64) {
                     const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
                     if (need) {
-                        const uint32_t* rowp = gadj + (int64_t)(row0 + k * 4 + wave - node0) * stride;
+                        const uint32_t* rowp = gadj + (int64_t)(__builtin_amdgcn_readlane(nid8, k) - node0) * stride;
                         for (int w0 = 64; w0 < stride; w0 += 64) {
                             uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
                             const int c2 = __popc(w2);
@@ -898,7 +975,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 }
                 base = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
                 const int padded = (base + UN - 1) / UN * UN;
-                if (base + lane < padded) flat[off + base + lane] = (uint32_t)(row0 + k * 4 + wave) * 256u;    // masked filler visits
+                if (base + lane < padded) flat[off + base + lane] = (uint32_t)__builtin_amdgcn_readlane(nid8, k) * 256u;   // masked filler visits
                 if (lane == k) wdeg = base;
                 off += padded;
                 total_steps += padded / UN;
@@ -1005,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
         __syncthreads();
         const int row = tid >> 3, c0 = (tid & 7) * 8;
-        const bool hasnbr = a.deg[row0 + (row < rows ? row : rows - 1)] > 0;
+        const bool hasnbr = a.deg[nl[row]] > 0;
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(pt + row * EH_TP + c0 + 4 * q4);
@@ -1064,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 float hv = hp[rr * EH_TP + col];
                 float o = (1.0f - zg) * ng + zg * hv;
                 ht[rr * EH_TP + col] = o;
-                if (rr < rows) a.hnew[(size_t)(row0 + rr) * 64 + col] = o;
+                if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
             }
         }
     }
@@ -1088,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float v = eh_silu_fast(acc[i] + cb);
-                sum += (eh_crow(i, lane) < rows) ? v : 0.f;
+                sum += wl[eh_crow(i, lane)] * v;                 // weight 0 beyond the tile's rows, class size for a representative
             }
             sum += __shfl_xor(sum, 32);
             if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
@@ -1105,7 +1182,8 @@ __global__ __launch_bounds__(256) void k_gather_active(edgehip_layout L, edgehip
                                                        const int32_t* __restrict__ act_nodes,
                                                        const int32_t* __restrict__ kptr, const float* __restrict__ h,
                                                        const float* __restrict__ ctx, const int32_t* __restrict__ deg,
-                                                       const int32_t* __restrict__ d0, float* __restrict__ X) {
+                                                       const int32_t* __restrict__ d0, const int32_t* __restrict__ rep_of,
+                                                       float* __restrict__ X) {
     int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (tile >= L.num_tiles) return;
     int g = L.tile_graph[tile];
@@ -1113,6 +1191,10 @@ __global__ __launch_bounds__(256) void k_gather_active(edgehip_layout L, edgehip
     int k0 = L.tile_row0[tile] - node0;
     int K = kptr[g + 1] - kptr[g];
     if (k0 >= K) return;
+    if (K < 2) {        // no active pair: the graph was skipped (rep_of / h are not defined for it); keep the row finite
+        if (k0 == 0) for (int c = lane; c < 256; c += 64) X[(size_t)kptr[g] * 256 + c] = 0.f;
+        return;
+    }
     int kend = k0 + L.tile_rows[tile];
     kend = kend < K ? kend : K;
     float cg = ctx[(size_t)g * 64 + lane];
@@ -1126,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_gather_active(edgehip_layout L, edgehip
         dt = dt > P.max_degree + 1 ? P.max_degree + 1 : dt;
         float xt = (float)dt / md, x0 = (float)d0[i] / md;
         float* o = X + (size_t)(kptr[g] + k) * 256;
-        o[lane] = h[(size_t)i * 64 + lane] + cg;
+        o[lane] = h[(size_t)rep_of[i] * 64 + lane] + cg;      // an isolated node's state lives in its class representative's row
         o[64 + lane] = wt * xt + bt;
         o[128 + lane] = w0 * x0 + b0;
         o[192 + lane] = es;
@@ -1153,6 +1235,8 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
 
     EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_node_in, dim3(tile_blocks), dim3(256), 0, s, *L, P->max_degree, folded + fm.nin_at,
                        folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, idle, w.hA, w.part));
+    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_compact, dim3(B), dim3(256), 0, s, *L, deg, d0, flags, idle, h_out ? 0 : 1, w.crow, w.cwgt,
+                       w.rep_of, w.ccount));
     (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
     EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_heavy_list, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, deg, L->node_graph, idle, w.heavy_count, w.heavy_nodes,
                        w.heavy_slot));
@@ -1168,7 +1252,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         }
         EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, folded + fm.te_table, t_graph, t_shared,
                            w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64, w.ctx + (size_t)(l & 1) * (B + 1) * 64,
-                           w.qbias, ldq, w.obias0, w.obias1, w.cbias, idle));
+                           w.qbias, ldq, w.obias0, w.obias1, w.cbias, idle, w.ccount));
         if (l == P->num_layers) break;
         const int h = P->heads[l];
         eh_layer_args la = {};
@@ -1178,6 +1262,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.w_ih = folded + fm.pWih; la.w_hh = folded + fm.pWhh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
         la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
+        la.crow = w.crow; la.cwgt = w.cwgt; la.ccount = w.ccount;
         // qt of the heavy rows: gathered-row GEMM into the compact buffer w.Qt, then one block per heavy row
         {
             eh_gemm_desc d = {};
@@ -1211,7 +1296,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     // tail on the active nodes
     EH_PROF(EH_K_GATHER, s, hipLaunchKernelGGL(k_gather_active, dim3(tile_blocks), dim3(256), 0, s, *L, *P, act_nodes, kptr, hcur,
                        w.ctx + (size_t)(P->num_layers & 1) * (B + 1) * 64, deg,
-                       d0, w.Xact));
+                       d0, w.rep_of, w.Xact));
     eh_gemm_desc g0 = {};
     g0.A = w.Xact; g0.lda = 256; g0.K1 = 256; g0.W = folded + fm.pNo0; g0.w_packed = 1; g0.K = 256; g0.N = 128; g0.bias = P->node_out_b0;
     g0.Y = w.U1; g0.ldy = 128; g0.act = 1; g0.M = Nn; g0.m_dev = &counts->k_total;

@@ -218,3 +218,40 @@ def test_sample_api_polblogs_shape():
     assert int(sl[-1]) == ei.shape[1]
     out2 = model.sample_batch(edgehip.GraphBatch([n] * 4, degree=[d] * 4, device='cuda'), seed=7)
     assert torch.equal(out2.edge_index, ei)
+
+
+@pytest.mark.parametrize('state', ['empty', 'sparse', 'dense'])
+def test_live_row_compaction_matches_full_computation(state):
+    """Isolated nodes that share (d0, active flag) are computed once (k_compact).  The same forward with the
+    compaction off (h_out requested: every node is a row) must give the same per-active-node vectors."""
+    from edgehip import capi
+    from edgehip.model import _workspace
+    graphs = cases.ragged_graphs(6)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    model = H.build_model(orc.random_tgnn_params(8), T, dmax)
+    b = H.graph_batch(graphs)
+    rng = np.random.default_rng(4)
+    keep = b.pair_bits().nonzero(as_tuple=True)[0].cpu().numpy()
+    frac = dict(empty=0.0, sparse=0.15, dense=0.6)[state]
+    H.set_state_from_pair_indices(b, keep[rng.random(len(keep)) < frac])
+    Nn = b.num_nodes
+    model._p_sample_and_set_actives(b, 2, cases.uniforms(rng, Nn, 2).cuda())
+    st, L = b._state, b.layout
+    K = int(st['kptr'][-1].item())
+    assert K > 6
+    P, folded = model._denoise_fn.c_params()
+    ws = _workspace(b, P)
+    outs = []
+    for full in (False, True):
+        node_repr = torch.zeros((Nn + 32, 128), dtype=torch.float32, device='cuda')
+        h_out = torch.zeros((Nn, 64), dtype=torch.float32, device='cuda') if full else None
+        capi.check(capi.lib.edgehip_gnn_forward(
+            byref(L), byref(P), folded.data_ptr(), b.adj.data_ptr(), st['deg_t'].data_ptr(), b.degree_i32.data_ptr(),
+            st['t_graph'].data_ptr(), 0, st['flags'].data_ptr(), st['act_nodes'].data_ptr(), st['kptr'].data_ptr(),
+            st['counts'].data_ptr(), node_repr.data_ptr(), capi.ptr(h_out), ws.data_ptr(), ws.numel(), capi.stream_ptr()))
+        outs.append(node_repr[:K].clone())
+    kp = st['kptr'].cpu().numpy()
+    rows = np.concatenate([np.arange(kp[g], kp[g + 1]) for g in range(b.num_graphs) if kp[g + 1] - kp[g] >= 2])
+    assert len(rows) > 4
+    assert H.rel_err(outs[0][rows], outs[1][rows]) < 2e-6
