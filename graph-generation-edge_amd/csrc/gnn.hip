@@ -324,29 +324,33 @@ __global__ __launch_bounds__(256) void k_compact(edgehip_layout L, const int32_t
         }
     }
     __syncthreads();
-    for (int base = 0; base < n; base += 256) {
-        const int li = base + tid;
-        int live = 0, holder = 0;
-        float wgt = 1.0f;
-        if (li < n) {
-            const int i = node0 + li;
-            const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
-            const bool cls = dedupe && deg[i] == 0 && key >= 0 && key < EH_CKEYS;
-            live = !cls || rep[key] == li;
-            holder = cls ? node0 + rep[key] : i;
-            wgt = cls ? (float)cnt[key] : 1.0f;
-            rep_of[i] = holder;
+    // connected nodes first, then the class representatives (each group in ascending node order): tiles are
+    // then either all-connected or all-isolated but one, and an all-isolated tile skips the attention phases
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int base = 0; base < n; base += 256) {
+            const int li = base + tid;
+            int live = 0;
+            float wgt = 1.0f;
+            if (li < n) {
+                const int i = node0 + li;
+                const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
+                const bool cls = dedupe && deg[i] == 0 && key >= 0 && key < EH_CKEYS;
+                const bool connected = deg[i] > 0;
+                live = (!cls || rep[key] == li) && (connected == (pass == 0));
+                wgt = cls ? (float)cnt[key] : 1.0f;
+                if (pass == 0) rep_of[i] = cls ? node0 + rep[key] : i;
+            }
+            const unsigned long long m = __ballot(live);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wv] = __popcll(m);
+            __syncthreads();
+            int off = running;
+            for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+            if (live) { crow[node0 + off + before] = node0 + li; cwgt[node0 + off + before] = wgt; }
+            __syncthreads();
+            if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
         }
-        const unsigned long long m = __ballot(live);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wv] = __popcll(m);
-        __syncthreads();
-        int off = running;
-        for (int w = 0; w < wv; ++w) off += wave_cnt[w];
-        if (live) { crow[node0 + off + before] = node0 + li; cwgt[node0 + off + before] = wgt; }
-        __syncthreads();
-        if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
     }
     if (tid == 0) ccount[g] = running;
 }
@@ -857,6 +861,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     const int r = lane & 31, hh = lane >> 5;
     const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
+    const int mydeg = a.deg[mynid];                                        // consumed after phase 0 (load in flight)
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -888,8 +893,12 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     __syncthreads();
     EH_STAMP_AT(0);
 
+    // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it
+    // needs neither qt nor the attention nor the z chunks of the conv product.  Block-uniform.
+    const bool anynbr = __any(mydeg > 0);
+
     // ---- phase A: qt
-    {
+    if (anynbr) {
         eh_frag af;
         eh_load_frag_lds(af, hp, r, hh);
         for (int nt = wave; nt < 2 * HEADS; nt += 4) {
@@ -912,7 +921,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
     // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
     // neighbours side by side (slots) and merges their softmax states when the target ends.
-    {
+    if (anynbr) {
         constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;   // slots, rounds per step
         constexpr int UN = eh_walk_cfg<HEADS>::UN;                     // visits per step (divides EH_HEAVY_DEG)
         static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
@@ -1059,6 +1068,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         f32x16 acc0 = eh_zero16(), acc1 = eh_zero16();
         for (int ch = wave; ch < HEADS + 1; ch += 4) {
             eh_frag af, bf;
+            if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
             if (ch < HEADS) {
                 const float* p = qz + r * QP + ch * 64 + hh * 32;
 #pragma unroll
