@@ -90,4 +90,69 @@ struct eh_gemm_desc {
     int prof_id;                        // kernel class for the optional event timer (prof.h)
 };
 
+// Packed-weight variant: W in fragment order, no LDS, no barriers; every wave streams its fragments
+// with coalesced 1-KiB loads (the 4 waves of a block read the same fragments: L1 hits).
+template <int NACC>
+__device__ static inline void eh_gemm_packed_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int tile = bx * 4 + wave;
+    int row0, rows, g = 0;
+    if (d.tile_row0) {
+        if (tile >= d.num_tiles) return;
+        row0 = d.tile_row0[tile]; rows = d.tile_rows[tile]; g = d.tile_graph[tile];
+    } else {
+        int64_t M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
+        int64_t r0 = (int64_t)tile * 32;
+        if (r0 >= M) return;
+        row0 = (int)r0; rows = (int)((M - r0) < 32 ? (M - r0) : 32);
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    int64_t arow = row0 + (r < rows ? r : rows - 1);
+    if (d.arow_index) arow = d.arow_index[arow];
+    const float* ap = d.A + arow * d.lda + hh * 32;
+    const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
+    const int KC = d.K >> 6;
+    const int ng_total = d.N / (32 * NACC);
+    const int ng0 = by * ng_per_block;
+    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
+    const bool single = d.K == 64;
+    eh_frag a;
+    if (single) eh_load_frag(a, ap);
+    for (int ng = ng0; ng < ng1; ++ng) {
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
+        for (int kc = 0; kc < KC; ++kc) {
+            if (!single) eh_load_frag(a, (kc * 64 < d.K1) ? ap + kc * 64 : ap2 + (kc * 64 - d.K1));
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                eh_frag b;
+                eh_load_frag_packed(b, d.W, KC, ng * NACC + j, kc, lane);
+                eh_mma64(acc[j], a, b);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            const int col = (ng * NACC + j) * 32 + r;
+            float add0 = d.bias ? d.bias[col] : 0.0f;
+            if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
+            const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rr = eh_crow(i, lane);
+                if (rr < rows) {
+                    int64_t grow = row0 + rr;
+                    float v = acc[j][i] + add0;
+                    if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
+                    if (d.act == 1) v = eh_silu(v);
+                    d.Y[grow * d.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+
+// grid of the packed kernel for a descriptor: blocks along the row tiles (gx), column-group splits, groups per block
+void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nacc);
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream);

@@ -74,66 +74,20 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
     }
 }
 
-// Packed-weight variant: W in fragment order, no LDS, no barriers; every wave streams its fragments
-// with coalesced 1-KiB loads (the 4 waves of a block read the same fragments: L1 hits).
 template <int NACC>
 __global__ __launch_bounds__(256) void k_gemm_packed(eh_gemm_desc d, int ng_per_block) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
-    int row0, rows, g = 0;
-    if (d.tile_row0) {
-        if (tile >= d.num_tiles) return;
-        row0 = d.tile_row0[tile]; rows = d.tile_rows[tile]; g = d.tile_graph[tile];
-    } else {
-        int64_t M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
-        int64_t r0 = (int64_t)tile * 32;
-        if (r0 >= M) return;
-        row0 = (int)r0; rows = (int)((M - r0) < 32 ? (M - r0) : 32);
-    }
-    const int r = lane & 31, hh = lane >> 5;
-    int64_t arow = row0 + (r < rows ? r : rows - 1);
-    if (d.arow_index) arow = d.arow_index[arow];
-    const float* ap = d.A + arow * d.lda + hh * 32;
-    const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
-    const int KC = d.K >> 6;
-    const int ng_total = d.N / (32 * NACC);
-    const int ng0 = blockIdx.y * ng_per_block;
-    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
-    const bool single = d.K == 64;
-    eh_frag a;
-    if (single) eh_load_frag(a, ap);
-    for (int ng = ng0; ng < ng1; ++ng) {
-        f32x16 acc[NACC];
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
-        for (int kc = 0; kc < KC; ++kc) {
-            if (!single) eh_load_frag(a, (kc * 64 < d.K1) ? ap + kc * 64 : ap2 + (kc * 64 - d.K1));
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) {
-                eh_frag b;
-                eh_load_frag_packed(b, d.W, KC, ng * NACC + j, kc, lane);
-                eh_mma64(acc[j], a, b);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-            const int col = (ng * NACC + j) * 32 + r;
-            float add0 = d.bias ? d.bias[col] : 0.0f;
-            if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
-            const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int rr = eh_crow(i, lane);
-                if (rr < rows) {
-                    int64_t grow = row0 + rr;
-                    float v = acc[j][i] + add0;
-                    if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
-                    if (d.act == 1) v = eh_silu(v);
-                    d.Y[grow * d.ldy + col] = v;
-                }
-            }
-        }
-    }
+    eh_gemm_packed_body<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y);
+}
+
+void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nacc) {
+    int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
+    gx = (int)((tiles + 3) / 4);
+    nacc = (d.N % 64 == 0) ? 2 : 1;
+    const int ng_total = d.N / (32 * nacc);
+    int want = (2048 + gx - 1) / gx;
+    split = want < 1 ? 1 : (want > ng_total ? ng_total : want);
+    per = (ng_total + split - 1) / split;
+    split = (ng_total + per - 1) / per;
 }
 
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
@@ -143,13 +97,8 @@ int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
     if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;
     int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
     if (tiles <= 0) return EDGEHIP_OK;
-    int gx = (int)((tiles + 3) / 4);
-    const int nacc = (d.N % 64 == 0) ? 2 : 1;
-    const int ng_total = d.N / (32 * nacc);
-    int want = (2048 + gx - 1) / gx;
-    int split = want < 1 ? 1 : (want > ng_total ? ng_total : want);
-    int per = (ng_total + split - 1) / split;
-    split = (ng_total + per - 1) / per;
+    int gx, split, per, nacc;
+    eh_gemm_grid(d, gx, split, per, nacc);
     if (d.w_packed) {
         if (nacc == 2)
             EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm_packed<2>, dim3(gx, split), dim3(256), 0, stream, d, per));

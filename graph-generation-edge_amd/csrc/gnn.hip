@@ -462,14 +462,21 @@ __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld
 // grid (B, EH_GU_PARTS): every part recomputes the (cheap) context chain, then takes its share of the
 // per-graph bias vectors of layer l, so that 4 x B blocks are in flight instead of B.
 #define EH_GU_PARTS 4
-__global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, int l, eh_layer_ptrs lp,
+struct eh_update_args {
+    int l; eh_layer_ptrs lp;
+    const float* part; const float* te; const int32_t* t_graph; int te_shared;
+    const float* ctx_in; float* ctx; float* qbias; int ldq; float* obias0; float* obias1; float* cbias;
+    const int32_t* idle; const int32_t* ccount;
+};
+
+__device__ static inline void eh_graph_update_body(const edgehip_layout& L, const edgehip_gnn_params& P, int l, const eh_layer_ptrs& lp,
                                                       const float* __restrict__ part, const float* __restrict__ te /*[T][L][64]*/,
                                                       const int32_t* __restrict__ t_graph, int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
                                                       int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
                                                       float* __restrict__ cbias, const int32_t* __restrict__ idle,
-                                                      const int32_t* __restrict__ ccount) {
+                                                      const int32_t* __restrict__ ccount, int g, int prt) {
     __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
-    const int g = blockIdx.x, prt = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
     // l == 0: sums of k_node_in over all (static) tiles; l >= 1: weighted sums of the LIVE tiles of k_layer
@@ -539,6 +546,26 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
     if (prt == 2)       // obias1 = bvbar + Vbbar . te + Vsum . ctx
         eh_block_gemv<64, true>(lp.Vbbar, 64, tev, lp.Vsum, 64, xc, lp.bvbar, 0, 64, obias1 + (size_t)g * 64, 0);
     if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+}
+
+__global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, eh_update_args u) {
+    eh_graph_update_body(L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
+                         u.obias1, u.cbias, u.idle, u.ccount, blockIdx.x / EH_GU_PARTS, blockIdx.x % EH_GU_PARTS);
+}
+
+// One launch, two independent jobs side by side (block specialisation): the per-graph update of layer l
+// (blocks [0, nb_update)) and the gathered-row qt GEMM of the heavy rows (the rest).  Neither reads what the
+// other writes; run back to back they were two latency-bound launches on the critical path of every layer.
+__global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, edgehip_gnn_params P, eh_update_args u,
+                                                            int nb_update, eh_gemm_desc d, int gx, int per) {
+    const int b = blockIdx.x;
+    if (b < nb_update) {
+        eh_graph_update_body(L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
+                             u.obias1, u.cbias, u.idle, u.ccount, b / EH_GU_PARTS, b % EH_GU_PARTS);
+    } else {
+        const int bb = b - nb_update;
+        eh_gemm_packed_body<2>(d, per, bb % gx, bb / gx);
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1260,10 +1287,15 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             lp.Vbbar = folded + f.Vbbar; lp.bvbar = folded + f.bvbar; lp.Vsum = folded + f.Vsum;
             lp.skip_w = P->skip_w[l]; lp.skip_b = P->skip_b[l]; lp.H = P->heads[l] * 64;
         }
-        EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B, EH_GU_PARTS), dim3(256), 0, s, *L, *P, l, lp, w.part, folded + fm.te_table, t_graph, t_shared,
-                           w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64, w.ctx + (size_t)(l & 1) * (B + 1) * 64,
-                           w.qbias, ldq, w.obias0, w.obias1, w.cbias, idle, w.ccount));
-        if (l == P->num_layers) break;
+        eh_update_args ua = {};
+        ua.l = l; ua.lp = lp; ua.part = w.part; ua.te = folded + fm.te_table; ua.t_graph = t_graph; ua.te_shared = t_shared;
+        ua.ctx_in = w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64; ua.ctx = w.ctx + (size_t)(l & 1) * (B + 1) * 64;
+        ua.qbias = w.qbias; ua.ldq = ldq; ua.obias0 = w.obias0; ua.obias1 = w.obias1; ua.cbias = w.cbias;
+        ua.idle = idle; ua.ccount = w.ccount;
+        if (l == P->num_layers) {
+            EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B * EH_GU_PARTS), dim3(256), 0, s, *L, *P, ua));
+            break;
+        }
         const int h = P->heads[l];
         eh_layer_args la = {};
         la.adj = adj; la.hprev = hcur; la.deg = deg;
@@ -1273,14 +1305,18 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
         la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
         la.crow = w.crow; la.cwgt = w.cwgt; la.ccount = w.ccount;
-        // qt of the heavy rows: gathered-row GEMM into the compact buffer w.Qt, then one block per heavy row
+        // per-graph update of this layer and qt of the heavy rows (gathered-row GEMM into the compact buffer
+        // w.Qt) in ONE launch: they are independent, and each alone is a latency-bound launch
         {
             eh_gemm_desc d = {};
             d.A = hcur; d.lda = 64; d.K1 = 64; d.arow_index = w.heavy_nodes; d.W = folded + fm.layer[l].pMcat; d.w_packed = 1;
             d.K = 64; d.N = h * 64; d.Y = w.Qt; d.ldy = h * 64; d.act = 0; d.M = Nn; d.m_dev = w.heavy_count;
-            d.prof_id = EH_K_GEMM_QT;
-            int rc = eh_launch_gemm(d, s);
-            if (rc != EDGEHIP_OK) return rc;
+            int gx, split, per, nacc;
+            eh_gemm_grid(d, gx, split, per, nacc);
+            if (nacc != 2) return EDGEHIP_ERR_UNSUPPORTED;
+            const int nbu = B * EH_GU_PARTS;
+            EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_update_and_heavy_qt, dim3(nbu + gx * split), dim3(256), 0, s, *L, *P, ua,
+                               nbu, d, gx, per));
         }
         const int hb = Nn < 4096 ? Nn : 4096;
         switch (h) {
