@@ -1212,43 +1212,124 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 }
 
 // --------------------------------------------------------------------------------------------
-// tail input of the active nodes: [h + ctx | emb_t(x_t) | emb_0(x_0) | emb_sel[1]]  (layers.py:377)
-// compact rows in active-node order; one wave per node tile (local index k of graph g).
+// Tail on the active nodes, one launch (layers.py:377-379 + the folded first layer of final_out):
+//   X = [h + ctx | emb_t(x_t) | emb_0(x_0) | emb_sel[1]]  ->  silu(No0 X)  ->  silu(No2 .)  ->  W4f .  = node_repr
+// One block per 32 rows of the compact active-node list (row R of graph g = its (R - kptr[g])-th active
+// node); the three products chain through LDS.  K_total is a few thousand rows at most, so this replaces
+// four latency-bound launches (gather + 3 GEMMs) by one.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_active(edgehip_layout L, edgehip_gnn_params P,
-                                                       const int32_t* __restrict__ act_nodes,
-                                                       const int32_t* __restrict__ kptr, const float* __restrict__ h,
-                                                       const float* __restrict__ ctx, const int32_t* __restrict__ deg,
-                                                       const int32_t* __restrict__ d0, const int32_t* __restrict__ rep_of,
-                                                       float* __restrict__ X) {
-    int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (tile >= L.num_tiles) return;
-    int g = L.tile_graph[tile];
-    int node0 = L.node_ptr[g];
-    int k0 = L.tile_row0[tile] - node0;
-    int K = kptr[g + 1] - kptr[g];
-    if (k0 >= K) return;
-    if (K < 2) {        // no active pair: the graph was skipped (rep_of / h are not defined for it); keep the row finite
-        if (k0 == 0) for (int c = lane; c < 256; c += 64) X[(size_t)kptr[g] * 256 + c] = 0.f;
-        return;
+#define EH_XP 260           // pitch of the 256-wide tile (260 mod 32 = 4: conflict-free b128 fragment reads)
+#define EH_UP 132           // pitch of the 128-wide tiles
+__global__ __launch_bounds__(256) void k_tail(edgehip_layout L, edgehip_gnn_params P, const int32_t* __restrict__ act_nodes,
+                                              const int32_t* __restrict__ kptr, const edgehip_counts* __restrict__ counts,
+                                              const float* __restrict__ h, const float* __restrict__ ctx,
+                                              const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
+                                              const int32_t* __restrict__ rep_of, const float* __restrict__ pNo0,
+                                              const float* __restrict__ pNo2, const float* __restrict__ pW4f,
+                                              const float* __restrict__ b4f, float* __restrict__ node_repr) {
+    __shared__ __attribute__((aligned(16))) float X[32 * EH_XP];
+    __shared__ __attribute__((aligned(16))) float U1[32 * EH_UP];
+    __shared__ __attribute__((aligned(16))) float U2[32 * EH_UP];
+    __shared__ int rg[32], rn[32];
+    const int ktotal = counts->k_total;
+    const int R0 = blockIdx.x * 32;
+    if (R0 >= ktotal) return;
+    const int rows = ktotal - R0 < 32 ? ktotal - R0 : 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    if (tid < 32) {
+        const int R = R0 + (tid < rows ? tid : rows - 1);
+        int lo = 0, hi = L.num_graphs;                   // kptr[lo] <= R < kptr[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (kptr[mid] <= R) lo = mid; else hi = mid;
+        }
+        const int K = kptr[lo + 1] - kptr[lo];
+        rg[tid] = lo;
+        // a graph with a single active node has no pair and was skipped (rep_of / h undefined): zero row
+        rn[tid] = K >= 2 ? act_nodes[L.node_ptr[lo] + (R - kptr[lo])] : -1;
     }
-    int kend = k0 + L.tile_rows[tile];
-    kend = kend < K ? kend : K;
-    float cg = ctx[(size_t)g * 64 + lane];
-    float wt = P.embedding_t_w[lane], bt = P.embedding_t_b[lane];
-    float w0 = P.embedding_0_w[lane], b0 = P.embedding_0_b[lane];
-    float es = P.embedding_sel_w[64 + lane];
-    float md = (float)P.max_degree;
-    for (int k = k0; k < kend; ++k) {
-        int i = act_nodes[node0 + k];
-        int dt = deg[i];
-        dt = dt > P.max_degree + 1 ? P.max_degree + 1 : dt;
-        float xt = (float)dt / md, x0 = (float)d0[i] / md;
-        float* o = X + (size_t)(kptr[g] + k) * 256;
-        o[lane] = h[(size_t)rep_of[i] * 64 + lane] + cg;      // an isolated node's state lives in its class representative's row
-        o[64 + lane] = wt * xt + bt;
-        o[128 + lane] = w0 * x0 + b0;
-        o[192 + lane] = es;
+    __syncthreads();
+    {   // X tile: 8 threads per row, 32 columns each
+        const int row = tid >> 3, part = tid & 7;
+        const int g = rg[row], i = rn[row];
+        float* xr = X + row * EH_XP + part * 32;
+        if (i < 0) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) xr[c] = 0.f;
+        } else if (part < 2) {
+            const float* hr = h + (size_t)rep_of[i] * 64 + part * 32;      // an isolated node's state lives in its class representative's row
+            const float* cg = ctx + (size_t)g * 64 + part * 32;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) xr[c] = hr[c] + cg[c];
+        } else if (part < 6) {
+            const bool is_t = part < 4;
+            const int c0 = (part & 1) * 32;
+            int dt = deg[i];
+            dt = dt > P.max_degree + 1 ? P.max_degree + 1 : dt;
+            const float x = (is_t ? (float)dt : (float)d0[i]) / (float)P.max_degree;
+            const float* wv = (is_t ? P.embedding_t_w : P.embedding_0_w) + c0;
+            const float* bv = (is_t ? P.embedding_t_b : P.embedding_0_b) + c0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) xr[c] = wv[c] * x + bv[c];
+        } else {
+            const float* es = P.embedding_sel_w + 64 + (part - 6) * 32;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) xr[c] = es[c];
+        }
+    }
+    __syncthreads();
+    const int col = wave * 32 + r;                       // every stage: wave w owns output columns 32w .. 32w+31
+    {   // U1 = silu(No0 X + b0), K = 256
+        f32x16 acc = eh_zero16();
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            eh_frag af, bf;
+            const float* p = X + r * EH_XP + kc * 64 + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            eh_load_frag_packed(bf, pNo0, 4, wave, kc, lane);
+            eh_mma64(acc, af, bf);
+        }
+        const float bb = P.node_out_b0[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U1[eh_crow(i, lane) * EH_UP + col] = eh_silu(acc[i] + bb);
+    }
+    __syncthreads();
+    {   // U2 = silu(No2 U1 + b2), K = 128
+        f32x16 acc = eh_zero16();
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            eh_frag af, bf;
+            const float* p = U1 + r * EH_UP + kc * 64 + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            eh_load_frag_packed(bf, pNo2, 2, wave, kc, lane);
+            eh_mma64(acc, af, bf);
+        }
+        const float bb = P.node_out_b2[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U2[eh_crow(i, lane) * EH_UP + col] = eh_silu(acc[i] + bb);
+    }
+    __syncthreads();
+    {   // node_repr = W4f U2 + b4f, K = 128
+        f32x16 acc = eh_zero16();
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            eh_frag af, bf;
+            const float* p = U2 + r * EH_UP + kc * 64 + hh * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            eh_load_frag_packed(bf, pW4f, 2, wave, kc, lane);
+            eh_mma64(acc, af, bf);
+        }
+        const float bb = b4f[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = eh_crow(i, lane);
+            if (rr < rows) node_repr[(size_t)(R0 + rr) * 128 + col] = acc[i] + bb;
+        }
     }
 }
 
@@ -1340,23 +1421,9 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         (void)hipMemcpyAsync(h_out, hcur, (size_t)Nn * 64 * 4, hipMemcpyDeviceToDevice, s);
     }
     // tail on the active nodes
-    EH_PROF(EH_K_GATHER, s, hipLaunchKernelGGL(k_gather_active, dim3(tile_blocks), dim3(256), 0, s, *L, *P, act_nodes, kptr, hcur,
-                       w.ctx + (size_t)(P->num_layers & 1) * (B + 1) * 64, deg,
-                       d0, w.rep_of, w.Xact));
-    eh_gemm_desc g0 = {};
-    g0.A = w.Xact; g0.lda = 256; g0.K1 = 256; g0.W = folded + fm.pNo0; g0.w_packed = 1; g0.K = 256; g0.N = 128; g0.bias = P->node_out_b0;
-    g0.Y = w.U1; g0.ldy = 128; g0.act = 1; g0.M = Nn; g0.m_dev = &counts->k_total;
-    g0.prof_id = EH_K_GEMM_TAIL;
-    int rc = eh_launch_gemm(g0, s);
-    if (rc != EDGEHIP_OK) return rc;
-    eh_gemm_desc g1 = g0;
-    g1.A = w.U1; g1.lda = 128; g1.K1 = 128; g1.W = folded + fm.pNo2; g1.K = 128; g1.bias = P->node_out_b2; g1.Y = w.U2;
-    rc = eh_launch_gemm(g1, s);
-    if (rc != EDGEHIP_OK) return rc;
-    eh_gemm_desc g2 = g1;
-    g2.A = w.U2; g2.W = folded + fm.pW4f; g2.bias = folded + fm.b4f; g2.Y = node_repr; g2.act = 0;
-    rc = eh_launch_gemm(g2, s);
-    if (rc != EDGEHIP_OK) return rc;
+    EH_PROF(EH_K_GEMM_TAIL, s, hipLaunchKernelGGL(k_tail, dim3((Nn + 31) / 32), dim3(256), 0, s, *L, *P, act_nodes, kptr, counts, hcur,
+                       w.ctx + (size_t)(P->num_layers & 1) * (B + 1) * 64, deg, d0, w.rep_of, folded + fm.pNo0, folded + fm.pNo2,
+                       folded + fm.pW4f, folded + fm.b4f, node_repr));
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }
