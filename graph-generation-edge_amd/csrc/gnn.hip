@@ -195,9 +195,9 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
 // workspace carving
 // --------------------------------------------------------------------------------------------
 struct eh_ws {
-    float *hA, *hB, *Qt, *Z, *Mb, *part, *te, *ctx, *qbias, *obias0, *obias1, *cbias, *Xact, *U1, *U2;
+    float *hA, *hB, *Qt, *Z, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
     // step-level scratch
-    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *deg2, *heavy_nodes, *heavy_slot, *heavy_count;
+    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_nodes, *heavy_slot, *heavy_count;
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
     float* cwgt;
     int64_t* aptr;
@@ -218,16 +218,12 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     size_t NnP = Nn + 32;   // slack row block so clamped fragment loads stay inside
     w.hA = (float*)take(NnP * 64 * 4); w.hB = (float*)take(NnP * 64 * 4);
     w.Qt = (float*)take(NnP * H * 4); w.Z = (float*)take(NnP * H * 4);
-    w.Mb = (float*)take(NnP * 64 * 4);
     w.part = (float*)take((NT + 1) * 256 * 4);
-    w.te = (float*)take((B + 1) * EDGEHIP_MAX_LAYERS * 64 * 4);
     w.ctx = (float*)take((size_t)2 * (B + 1) * 64 * 4);    // two copies: layer l reads one, writes the other
     w.qbias = (float*)take((B + 1) * H * 4);
     w.obias0 = (float*)take((B + 1) * 64 * 4); w.obias1 = (float*)take((B + 1) * 64 * 4);
     w.cbias = (float*)take((B + 1) * 256 * 4);
-    w.Xact = (float*)take(NnP * 256 * 4);
-    w.U1 = (float*)take(NnP * 128 * 4); w.U2 = (float*)take(NnP * 128 * 4);
-    w.deg = (int32_t*)take(NnP * 4); w.deg2 = (int32_t*)take(NnP * 4);
+    w.deg = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
     w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4); w.heavy_count = (int32_t*)take(256);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
@@ -300,14 +296,14 @@ __global__ __launch_bounds__(256) void k_time_embed(edgehip_gnn_params P, const 
 // isolated.  rep_of[i] = the row that holds node i's state.  dedupe = 0 keeps every node (h_out requested).
 // --------------------------------------------------------------------------------------------
 #define EH_CKEYS 4096          // (d0, flag) keys with a table slot; larger d0 -> the node stays its own row
-__global__ __launch_bounds__(256) void k_compact(edgehip_layout L, const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
-                                                 const uint8_t* __restrict__ flags, const int32_t* __restrict__ idle, int dedupe,
-                                                 int32_t* __restrict__ crow, float* __restrict__ cwgt,
-                                                 int32_t* __restrict__ rep_of, int32_t* __restrict__ ccount) {
+__device__ static inline void eh_compact_body(const edgehip_layout& L, const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
+                                               const uint8_t* __restrict__ flags, const int32_t* __restrict__ idle, int dedupe,
+                                               int32_t* __restrict__ crow, float* __restrict__ cwgt,
+                                               int32_t* __restrict__ rep_of, int32_t* __restrict__ ccount, int g) {
     __shared__ int rep[EH_CKEYS], cnt[EH_CKEYS];
     __shared__ int wave_cnt[4];
     __shared__ int running;
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int node0 = L.node_ptr[g], n = L.node_ptr[g + 1] - node0;
     if (idle != nullptr && idle[g + 1] - idle[g] < 2) {
         if (tid == 0) ccount[g] = 0;
@@ -362,15 +358,42 @@ __device__ static inline bool eh_graph_idle(const int32_t* __restrict__ kptr, in
     return kptr != nullptr && kptr[g + 1] - kptr[g] < 2;
 }
 
-__global__ __launch_bounds__(256) void k_node_in(edgehip_layout L, int max_degree, const float* __restrict__ at,
-                                                 const float* __restrict__ a0, const float* __restrict__ as,
-                                                 const int32_t* __restrict__ deg, const int32_t* __restrict__ d0,
-                                                 const uint8_t* __restrict__ flags, const int32_t* __restrict__ idle,
-                                                 float* __restrict__ h0, float* __restrict__ part) {
+// rows with more neighbours than this are walked by k_attn_heavy instead of the fused layer kernel
+#ifndef EH_HEAVY_DEG
+#define EH_HEAVY_DEG 48         // multiple of every eh_walk_cfg<h>::UN (lists are padded to whole steps)
+#endif
+
+// One launch for the three per-step preparations that only need (deg, d0, flags, kptr): blocks
+// [0, tile_blocks) compute h0 and list the heavy rows of their tiles, the last B blocks build the live-row
+// lists (k_compact body).
+struct eh_prep_args {
+    int max_degree; const float *at, *a0, *as;
+    const int32_t *deg, *d0; const uint8_t* flags; const int32_t* idle;
+    float *h0, *part;
+    int32_t *heavy_count, *heavy_nodes, *heavy_slot;
+    int dedupe; int32_t* crow; float* cwgt; int32_t *rep_of, *ccount;
+    int tile_blocks;
+};
+__global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_args p) {
+    if ((int)blockIdx.x >= p.tile_blocks) {
+        eh_compact_body(L, p.deg, p.d0, p.flags, p.idle, p.dedupe, p.crow, p.cwgt, p.rep_of, p.ccount, blockIdx.x - p.tile_blocks);
+        return;
+    }
+    const int max_degree = p.max_degree;
+    const float *at = p.at, *a0 = p.a0, *as = p.as;
+    const int32_t *deg = p.deg, *d0 = p.d0;
+    const uint8_t* flags = p.flags;
+    float *h0 = p.h0, *part = p.part;
     int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (tile >= L.num_tiles) return;
-    if (eh_graph_idle(idle, L.tile_graph[tile])) return;
+    if (eh_graph_idle(p.idle, L.tile_graph[tile])) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
+    if (lane < rows) {      // heavy rows get a slot in the compact list (any order: slots are independent)
+        const int i = row0 + lane;
+        int slot = -1;
+        if (deg[i] > EH_HEAVY_DEG) { slot = atomicAdd(p.heavy_count, 1); p.heavy_nodes[slot] = i; }
+        p.heavy_slot[i] = slot;
+    }
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
     float sum = 0.f;
@@ -479,7 +502,7 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
     const int tid = threadIdx.x;
     if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
-    // l == 0: sums of k_node_in over all (static) tiles; l >= 1: weighted sums of the LIVE tiles of k_layer
+    // l == 0: sums of k_step_prepare (h0) over all (static) tiles; l >= 1: weighted sums of the LIVE tiles of k_layer
     const int t0 = L.tile_ptr[g], t1 = (l == 0) ? L.tile_ptr[g + 1] : t0 + (ccount[g] + 31) / 32;
     const int width = (l == 0) ? 64 : 256;
     if (tid < width) {
@@ -577,24 +600,11 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
 //
 // Degrees are skewed (polblogs: mean 27, max ~350).  Rows with at most EH_HEAVY_DEG neighbours are walked
 // inside the fused layer kernel (phase B: a wave's 8 targets as one flat stream).  Heavier rows are listed
-// once per step (k_heavy_list) and, per layer, get one WAVE each (k_attn_heavy), their qt coming from a
+// once per step (k_step_prepare) and, per layer, get one WAVE each (k_attn_heavy), their qt coming from a
 // gathered-row GEMM; z goes to zheavy[slot] and the fused kernel copies it instead of walking the row.
 // --------------------------------------------------------------------------------------------
 #define EH_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-#ifndef EH_HEAVY_DEG
-#define EH_HEAVY_DEG 48         // multiple of every eh_walk_cfg<h>::UN (lists are padded to whole steps)
-#endif
-
-__global__ __launch_bounds__(256) void k_heavy_list(int Nn, const int32_t* __restrict__ deg, const int32_t* __restrict__ node_graph,
-                                                    const int32_t* __restrict__ idle, int32_t* __restrict__ counter,
-                                                    int32_t* __restrict__ heavy_nodes, int32_t* __restrict__ heavy_slot) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Nn) return;
-    int slot = -1;
-    if (deg[i] > EH_HEAVY_DEG && !eh_graph_idle(idle, node_graph[i])) { slot = atomicAdd(counter, 1); heavy_nodes[slot] = i; }
-    heavy_slot[i] = slot;    // list order is arbitrary; every slot is computed independently of the others
-}
 
 // Walk one decoded neighbour list (row byte offsets in LDS, padded with filler entries to a whole step) for
 // ONE target, continuing the online-softmax state (m, l, acc).
@@ -1351,13 +1361,16 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_node_in, dim3(tile_blocks), dim3(256), 0, s, *L, P->max_degree, folded + fm.nin_at,
-                       folded + fm.nin_a0, folded + fm.nin_as, deg, d0, flags, idle, w.hA, w.part));
-    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_compact, dim3(B), dim3(256), 0, s, *L, deg, d0, flags, idle, h_out ? 0 : 1, w.crow, w.cwgt,
-                       w.rep_of, w.ccount));
     (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
-    EH_PROF(EH_K_MISC, s, hipLaunchKernelGGL(k_heavy_list, dim3((Nn + 255) / 256), dim3(256), 0, s, Nn, deg, L->node_graph, idle, w.heavy_count, w.heavy_nodes,
-                       w.heavy_slot));
+    {
+        eh_prep_args pa = {};
+        pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
+        pa.deg = deg; pa.d0 = d0; pa.flags = flags; pa.idle = idle; pa.h0 = w.hA; pa.part = w.part;
+        pa.heavy_count = w.heavy_count; pa.heavy_nodes = w.heavy_nodes; pa.heavy_slot = w.heavy_slot;
+        pa.dedupe = h_out ? 0 : 1; pa.crow = w.crow; pa.cwgt = w.cwgt; pa.rep_of = w.rep_of; pa.ccount = w.ccount;
+        pa.tile_blocks = tile_blocks;
+        EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_step_prepare, dim3(tile_blocks + B), dim3(256), 0, s, *L, pa));
+    }
     float* hcur = w.hA;
     float* hnext = w.hB;
     for (int l = 0; l <= P->num_layers; ++l) {
