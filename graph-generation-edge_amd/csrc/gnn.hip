@@ -898,20 +898,42 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     const int r = lane & 31, hh = lane >> 5;
     const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
-    const int mydeg = a.deg[mynid];                                        // consumed after phase 0 (load in flight)
+    const int mydeg = a.deg[mynid];
+    const int myhs = a.heavy_slot[mynid];
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-    // bit rows of this wave's 8 attention targets (rows k*4 + wave: interleaved over the waves so that a run
-    // of high-degree nodes does not land on one wave); issued here so the loads fly under phases 0 and A
+    // ---- phase 0 loads: the h tile (full lines), in flight under the target assignment below
+    f32x4 h0v[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * 256;
+        h0v[it] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, i >> 4) * 64 + (i & 15) * 4);
+    }
+
+    // A wave walks 8 of the tile's rows; its time is the SUM of their degrees, so the rows are dealt to the
+    // waves longest-first in snake order (rank the 32 walk lengths, wave w takes ranks 4k + w on even k and
+    // 4k + 3 - w on odd k).  Every wave computes the same assignment from the same registers.
+    const int work = (r < rows && myhs < 0) ? mydeg : 0;                   // heavy / absent rows are not walked here
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int wj = __builtin_amdgcn_readlane(work, j);
+        rank += (wj > work || (wj == work && j < r)) ? 1 : 0;
+    }
+    const int perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);   // lane p: the row of rank p & 31
+    const int trow8 = __shfl(perm, 4 * (lane & 7) + ((lane & 1) ? 3 - wave : wave));   // lane k < 8: row of target k
+
+    // bit rows of this wave's 8 attention targets; issued here so the loads fly under phases 0 and A
     const int node0 = L.node_ptr[g];
     const int stride = L.adj_stride[g];
     const uint32_t* gadj = a.adj + L.adj_ptr[g];
-    const bool mine8 = lane < 8 && lane * 4 + wave < rows;
-    const int nid8 = __shfl(mynid, (lane & 7) * 4 + wave);                // lane k < 8: node id of target k
-    const int hs8 = mine8 ? a.heavy_slot[nid8] : -1;
-    const int dg8 = mine8 ? a.deg[nid8] : 0;
+    const bool mine8 = lane < 8 && trow8 < rows;
+    const int nid8 = __shfl(mynid, trow8);                                // lane k < 8: node id of target k
+    const int hs8t = __shfl(myhs, trow8), dg8t = __shfl(mydeg, trow8);
+    const int hs8 = mine8 ? hs8t : -1;
+    const int dg8 = mine8 ? dg8t : 0;
     uint32_t fw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -919,13 +941,11 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid8, k) - node0) * stride + lane] : 0u;
     }
 
-    // ---- phase 0: h tile -> LDS (full-line loads)
+    // ---- phase 0: h tile -> LDS
 #pragma unroll
-    for (int i = tid; i < 512; i += 256) {
-        int row = i >> 4, c4 = i & 15;
-        int src = __shfl(mynid, row);
-        *reinterpret_cast<f32x4*>(hp + row * EH_TP + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(a.hprev + (size_t)src * 64 + c4 * 4);
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * 256;
+        *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
     }
     __syncthreads();
     EH_STAMP_AT(0);
@@ -953,7 +973,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     EH_STAMP_AT(1);
 
     // ---- phase B: attention of the light rows, z overwrites qt.
-    // A wave owns 8 targets (rows k*4 + wave) and walks them as ONE flat stream of neighbour visits: the
+    // A wave owns 8 targets (dealt longest-first above) and walks them as ONE flat stream of neighbour visits: the
     // decoded neighbour lists are concatenated in LDS (each padded to a whole step), so the gathers of the
     // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
     // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
@@ -1036,6 +1056,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
             int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
+            int krow = 0;                               // tile row of target k
             auto fetch = [&](int gs, eh_xr (&x)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, flat[(gs * U + u) * NSLOT + slot], wc);
@@ -1048,7 +1069,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                         nst = (dk + UN - 1) / UN;
                     } while (nst == 0);
                     st = 0;
-                    eh_load_cpl(q, qz + (k * 4 + wave) * QP + head * 64 + wc * EH_CPL);
+                    krow = __builtin_amdgcn_readlane(trow8, k);
+                    eh_load_cpl(q, qz + krow * QP + head * 64 + wc * EH_CPL);
 #pragma unroll
                     for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
                     mrun = -1e30f; lrun = 0.f;            // finite floor: exp(-1e30 - x) = 0 and never inf - inf
@@ -1058,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 if (st == nst) {                         // target finished: merge the slots, write z over its qt row
                     eh_merge_slots<HEADS>(acc, mrun, lrun);
                     if (slot == 0)
-                        eh_store_cpl_scaled(qz + (k * 4 + wave) * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
+                        eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
                 }
             };
             if (total_steps > 0) {
@@ -1081,8 +1103,9 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         {
             const int tdeg = __shfl(wdeg, grp);
             const int hslot = __shfl(hs8, grp);
+            const int trow = __shfl(trow8, grp);          // outside the branch: the source lanes must be active
             if (tdeg == 0) {
-                float* zrow = qz + (grp * 4 + wave) * QP + c * 8;
+                float* zrow = qz + trow * QP + c * 8;
 #pragma unroll
                 for (int h = 0; h < HEADS; ++h) {
                     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
