@@ -650,6 +650,15 @@ __device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc
     eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u))));
 }
 
+// The walk keeps its scores in the log2 domain: qt rows are multiplied by log2(e) once per target, so every
+// softmax weight is one v_exp_f32 (2^x) without the per-visit multiply of exp(x) = 2^(x log2 e).
+__device__ static inline float eh_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ static inline void eh_scale_q_log2e(f32x2 (&q)[EH_CPL / 2]) {
+    const f32x2 k = f32x2{1.4426950408889634f, 1.4426950408889634f};
+#pragma unroll
+    for (int d = 0; d < EH_CPL / 2; ++d) q[d] *= k;
+}
+
 __device__ static inline float eh_group_sum(float v) {          // over the EH_LG lanes of a group
     v += eh_dpp_f(v, 0);
     if (EH_LG >= 4) v += eh_dpp_f(v, 1);
@@ -678,10 +687,10 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
-    const float resc = __expf(m - mn);
+    const float resc = eh_exp2(m - mn);
     float ps = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { sc[u] = __expf(sc[u] - mn); ps += sc[u]; }
+    for (int u = 0; u < U; ++u) { sc[u] = eh_exp2(sc[u] - mn); ps += sc[u]; }
     lsum = lsum * resc + ps;
     const f32x2 r2 = f32x2{resc, resc};
 #pragma unroll
@@ -734,7 +743,7 @@ __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m,
     for (int o = EH_LG * HEADS; o < 64; o <<= 1) {
         const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(lsum, o);
         const float mm = fmaxf(m, m2);
-        const float s1 = __expf(m - mm), s2 = __expf(m2 - mm);
+        const float s1 = eh_exp2(m - mm), s2 = eh_exp2(m2 - mm);
         lsum = lsum * s1 + l2 * s2;
 #pragma unroll
         for (int d = 0; d < EH_CPL / 2; ++d) {
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
             eh_load_cpl(qb, qbias + (size_t)g * ldq + head * 64 + c * EH_CPL);
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] += qb[d]; acc[d] = f32x2{0.f, 0.f}; }
+            eh_scale_q_log2e(q);
         }
         for (int w0 = 0; w0 < stride; w0 += 64) {
             uint32_t w = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
@@ -1071,6 +1081,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                     st = 0;
                     krow = __builtin_amdgcn_readlane(trow8, k);
                     eh_load_cpl(q, qz + krow * QP + head * 64 + wc * EH_CPL);
+                    eh_scale_q_log2e(q);
 #pragma unroll
                     for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
                     mrun = -1e30f; lrun = 0.f;            // finite floor: exp(-1e30 - x) = 0 and never inf - inf
