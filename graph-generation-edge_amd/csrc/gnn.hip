@@ -619,6 +619,9 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
 #define EH_CPL 8
 #endif
 #define EH_LG (64 / EH_CPL)          // lanes per (slot, head) group
+#ifndef EH_PF
+#define EH_PF 2                      // register sets of the fused kernel's walk (prefetch distance EH_PF-1 steps)
+#endif
 template <int HEADS>
 struct eh_walk_cfg {
     static constexpr int NSLOT = EH_CPL / HEADS;
@@ -647,7 +650,17 @@ __device__ static inline void eh_store_cpl_scaled(float* __restrict__ p, const f
 // Lists hold BYTE offsets of the neighbour rows (id * 256): the gather is `base + offset` with a 32-bit
 // offset (scalar base, no 64-bit address arithmetic per visit).
 __device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc, uint32_t row_off, int c) {
+#if defined(EH_EXP_NOLOAD)      // timing experiments only (wrong results)
+#pragma unroll
+    for (int i = 0; i < EH_CPL / 2; ++i) x.p[i] = f32x2{__uint_as_float(row_off + i), __uint_as_float(row_off ^ (uint32_t)c)};
+#elif defined(EH_EXP_FIXEDROW)
+    eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + ((row_off & 0x300u) + (uint32_t)c * (EH_CPL * 4u))));
+#elif defined(EH_EXP_HALFLOAD)      // half the bytes through the vector L1
+    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u)));
+    x.p[0] = f32x2{a[0], a[1]}; x.p[1] = f32x2{a[2], a[3]}; x.p[2] = f32x2{a[1], a[0]}; x.p[3] = f32x2{a[3], a[2]};
+#else
     eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u))));
+#endif
 }
 
 // The walk keeps its scores in the log2 domain: qt rows are multiplied by log2(e) once per target, so every
@@ -672,6 +685,15 @@ template <int HEADS>
 __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const eh_xr (&x)[eh_walk_cfg<HEADS>::U], int nvalid,
                                            int slot, f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
+#ifdef EH_EXP_NOCOMPUTE         // timing experiment only: consume the loads, skip the softmax arithmetic
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[0] += x[u].p[0] + x[u].p[2];
+        acc[1] += x[u].p[1] + x[u].p[3];
+    }
+    lsum = 1.f;
+    return;
+#endif
     float sc[U];
     float mn = m;
 #pragma unroll
@@ -682,6 +704,7 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
         sc[u] = eh_group_sum(t2[0] + t2[1]);
     }
     if (nvalid < UN) {                       // wave-uniform: only the last step of a list has filler visits
+        asm volatile("" ::: "memory");       // keep this a branch: if-converted it costs 7 selects on EVERY step
 #pragma unroll
         for (int u = 0; u < U; ++u) sc[u] = (u * NSLOT + slot < nvalid) ? sc[u] : -INFINITY;
     }
@@ -988,7 +1011,11 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
     // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
     // neighbours side by side (slots) and merges their softmax states when the target ends.
+#ifdef EH_EXP_SKIPB
+    if (anynbr && a.ldq < 0) {
+#else
     if (anynbr) {
+#endif
         constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;   // slots, rounds per step
         constexpr int UN = eh_walk_cfg<HEADS>::UN;                     // visits per step (divides EH_HEAVY_DEG)
         static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
@@ -1067,9 +1094,15 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
             int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
             int krow = 0;                               // tile row of target k
-            auto fetch = [&](int gs, eh_xr (&x)[U]) {
+            // the row offsets of a step are read from the LDS list one step before its gathers are issued
+            // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
+            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, flat[(gs * U + u) * NSLOT + slot], wc);
+                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
+            };
+            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
             };
             auto compute = [&](const eh_xr (&x)[U]) {
                 if (st == nst) {                         // next target with work
@@ -1094,17 +1127,36 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                         eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
                 }
             };
+#ifdef EH_EXP_SKIPWALK
+            if (total_steps > 0 && a.ldq < 0) {
+#else
             if (total_steps > 0) {
-                eh_xr xa[U], xb[U];
+#endif
+                // EH_PF register sets: the gathers run EH_PF-1 steps ahead of their use.  One step of
+                // compute (~400 issue cycles) does not cover a loaded L2 round trip, and a wave has only
+                // one partner on its SIMD (2 blocks per CU), so the walk was latency-bound at depth 2.
+                eh_xr xs[EH_PF][U];
+                uint32_t on[U];
                 const int lastg = total_steps - 1;
-                fetch(0, xa);
+#pragma unroll
+                for (int b = 0; b < EH_PF - 1; ++b) {
+                    offs_of(b < lastg ? b : lastg, on);
+                    issue(on, xs[b]);
+                    __builtin_amdgcn_sched_barrier(0);     // issue order = consumption order (vmcnt counts in order)
+                }
+                offs_of(EH_PF - 1 < lastg ? EH_PF - 1 : lastg, on);
+                // ONE loop exit: with an exit inside the unrolled body the backend funnels it through the
+                // latch and then drains the whole load queue at the loop header (s_waitcnt vmcnt(1)).  The
+                // steps past the end are skipped by predication instead; their (clamped) fetches are hits.
 #pragma unroll 1
-                for (int gs = 0; gs < total_steps; gs += 2) {
-                    fetch(gs + 1 < lastg ? gs + 1 : lastg, xb);
-                    compute(xa);
-                    if (gs + 1 >= total_steps) break;
-                    fetch(gs + 2 < lastg ? gs + 2 : lastg, xa);
-                    compute(xb);
+                for (int gs = 0; gs < total_steps; gs += EH_PF) {
+#pragma unroll
+                    for (int b = 0; b < EH_PF; ++b) {
+                        issue(on, xs[(b + EH_PF - 1) % EH_PF]);
+                        const int nx = gs + b + EH_PF;
+                        offs_of(nx < lastg ? nx : lastg, on);
+                        if (gs + b < total_steps) compute(xs[b]);
+                    }
                 }
             }
         }
