@@ -778,21 +778,22 @@ __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m,
     }
 }
 
-// Heavy rows: ONE WAVE per row, no block-level synchronisation.  Per 64-word chunk of the bit row the wave
-// decodes the neighbour ids into its LDS list (popcount + prefix sum) and walks them with eh_walk_list.
+// Heavy rows: ONE WAVE per row, and one wave per BLOCK: the rows differ widely in length (49 .. 350
+// neighbours on polblogs), and a 4-wave block keeps its CU slots until its longest row is done (measured: 5.9
+// of 12 resident waves per CU on average).  Single-wave blocks are replaced as they finish.  Per 64-word
+// chunk of the bit row the wave decodes the neighbour ids into its LDS list (popcount + prefix sum) and
+// walks them with eh_walk_list.
 template <int HEADS>
-__global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
+__global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
                                                     const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
                                                     const float* __restrict__ qbias, int ldq,
                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
                                                     float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
-    __shared__ uint32_t lists[4][2048 + 16];       // a 64-word chunk holds at most 2048 neighbours (+ step padding)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ uint32_t list[2048 + 16];           // a 64-word chunk holds at most 2048 neighbours (+ step padding)
+    const int lane = threadIdx.x;
     const int nheavy = *counter;
-    uint32_t* list = lists[wave];
     const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS, head = grp % HEADS;
     // XCD affinity: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the contiguous slice
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(256) void k_attn_heavy(edgehip_layout L, const uint
     // of ~B/8 graphs (a few MB: L2-resident) instead of all of them.  Affinity only; any placement is correct.
     const int xcd = blockIdx.x & 7, nloc = (gridDim.x + 7 - xcd) >> 3;      // blocks of this XCD
     const int s0 = (int)((int64_t)nheavy * xcd / 8), s1 = (int)((int64_t)nheavy * (xcd + 1) / 8);
-    for (int idx = s0 + (blockIdx.x >> 3) * 4 + wave; idx < s1; idx += nloc * 4) {
+    for (int idx = s0 + (blockIdx.x >> 3); idx < s1; idx += nloc) {
         const int node = heavy_nodes[idx];
         const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
@@ -1498,12 +1499,12 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_update_and_heavy_qt, dim3(nbu + gx * split), dim3(256), 0, s, *L, *P, ua,
                                nbu, d, gx, per));
         }
-        const int hb = Nn < 4096 ? Nn : 4096;
+        const int hb = Nn < 16384 ? Nn : 16384;          // single-wave blocks
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(256), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
         }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
