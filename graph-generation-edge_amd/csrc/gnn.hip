@@ -198,6 +198,7 @@ struct eh_ws {
     float *hA, *hB, *Qt, *Z, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
     // step-level scratch
     int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_nodes, *heavy_slot, *heavy_count;
+    int32_t* long_slots;   // slots of the longest heavy rows (k_attn_heavy starts them first)
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
     float* cwgt;
     int64_t* aptr;
@@ -226,6 +227,7 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.deg = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
     w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4); w.heavy_count = (int32_t*)take(256);
+    w.long_slots = (int32_t*)take(NnP * 4);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
     w.ccount = (int32_t*)take((B + 1) * 4);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
@@ -309,11 +311,26 @@ __device__ static inline void eh_compact_body(const edgehip_layout& L, const int
         if (tid == 0) ccount[g] = 0;
         return;
     }
+    // every thread's nodes (li = tid + 256 c) are read ONCE, all loads in flight together; graphs with more
+    // than 256 * EH_CREG nodes read the rest where it is used
+    constexpr int EH_CREG = 8;
+    int rkey[EH_CREG], rdeg[EH_CREG];
+#pragma unroll
+    for (int c = 0; c < EH_CREG; ++c) {
+        const int li = tid + 256 * c;
+        rkey[c] = -1; rdeg[c] = 0;
+        if (li < n) { rkey[c] = d0[node0 + li] * 2 + (flags[node0 + li] ? 1 : 0); rdeg[c] = deg[node0 + li]; }
+    }
     for (int k = tid; k < EH_CKEYS; k += 256) { rep[k] = 0x7fffffff; cnt[k] = 0; }
     if (tid == 0) running = 0;
     __syncthreads();
     if (dedupe) {
-        for (int li = tid; li < n; li += 256) {
+#pragma unroll
+        for (int c = 0; c < EH_CREG; ++c) {
+            const int li = tid + 256 * c;
+            if (li < n && rdeg[c] == 0 && rkey[c] >= 0 && rkey[c] < EH_CKEYS) { atomicMin(&rep[rkey[c]], li); atomicAdd(&cnt[rkey[c]], 1); }
+        }
+        for (int li = tid + 256 * EH_CREG; li < n; li += 256) {
             const int i = node0 + li;
             const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
             if (deg[i] == 0 && key >= 0 && key < EH_CKEYS) { atomicMin(&rep[key], li); atomicAdd(&cnt[key], 1); }
@@ -323,15 +340,14 @@ __device__ static inline void eh_compact_body(const edgehip_layout& L, const int
     // connected nodes first, then the class representatives (each group in ascending node order): tiles are
     // then either all-connected or all-isolated but one, and an all-isolated tile skips the attention phases
     for (int pass = 0; pass < 2; ++pass) {
-        for (int base = 0; base < n; base += 256) {
-            const int li = base + tid;
+        auto chunk = [&](int c, int key, int dg) {
+            const int li = 256 * c + tid;
             int live = 0;
             float wgt = 1.0f;
             if (li < n) {
                 const int i = node0 + li;
-                const int key = d0[i] * 2 + (flags[i] ? 1 : 0);
-                const bool cls = dedupe && deg[i] == 0 && key >= 0 && key < EH_CKEYS;
-                const bool connected = deg[i] > 0;
+                const bool cls = dedupe && dg == 0 && key >= 0 && key < EH_CKEYS;
+                const bool connected = dg > 0;
                 live = (!cls || rep[key] == li) && (connected == (pass == 0));
                 wgt = cls ? (float)cnt[key] : 1.0f;
                 if (pass == 0) rep_of[i] = cls ? node0 + rep[key] : i;
@@ -346,6 +362,15 @@ __device__ static inline void eh_compact_body(const edgehip_layout& L, const int
             __syncthreads();
             if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             __syncthreads();
+        };
+#pragma unroll
+        for (int c = 0; c < EH_CREG; ++c)
+            if (256 * c < n) chunk(c, rkey[c], rdeg[c]);
+        for (int c = EH_CREG; 256 * c < n; ++c) {
+            const int li = 256 * c + tid;
+            int key = -1, dg = 0;
+            if (li < n) { key = d0[node0 + li] * 2 + (flags[node0 + li] ? 1 : 0); dg = deg[node0 + li]; }
+            chunk(c, key, dg);
         }
     }
     if (tid == 0) ccount[g] = running;
@@ -362,6 +387,9 @@ __device__ static inline bool eh_graph_idle(const int32_t* __restrict__ kptr, in
 #ifndef EH_HEAVY_DEG
 #define EH_HEAVY_DEG 48         // multiple of every eh_walk_cfg<h>::UN (lists are padded to whole steps)
 #endif
+#ifndef EH_LONG_DEG
+#define EH_LONG_DEG 128         // heavy rows with more neighbours go first in k_attn_heavy
+#endif
 
 // One launch for the three per-step preparations that only need (deg, d0, flags, kptr): blocks
 // [0, tile_blocks) compute h0 and list the heavy rows of their tiles, the last B blocks build the live-row
@@ -370,7 +398,7 @@ struct eh_prep_args {
     int max_degree; const float *at, *a0, *as;
     const int32_t *deg, *d0; const uint8_t* flags; const int32_t* idle;
     float *h0, *part;
-    int32_t *heavy_count, *heavy_nodes, *heavy_slot;
+    int32_t *heavy_count, *heavy_nodes, *heavy_slot, *long_slots;
     int dedupe; int32_t* crow; float* cwgt; int32_t *rep_of, *ccount;
     int tile_blocks;
 };
@@ -388,11 +416,24 @@ __global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_
     if (tile >= L.num_tiles) return;
     if (eh_graph_idle(p.idle, L.tile_graph[tile])) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
-    if (lane < rows) {      // heavy rows get a slot in the compact list (any order: slots are independent)
+    {   // heavy rows get a slot in the compact list (any order: slots are independent); one atomic per wave.
+        // The longest rows are listed a second time: k_attn_heavy starts them first (they set its tail).
         const int i = row0 + lane;
+        const int d = lane < rows ? deg[i] : 0;
+        const bool hv = d > EH_HEAVY_DEG, lg = d > EH_LONG_DEG;
+        const unsigned long long mh = __ballot(hv), ml = __ballot(lg);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int baseh = 0, basel = 0;
+        if (lane == 0 && mh) {       // both counters in one 64-bit atomic (low word: heavy rows, high word: long rows)
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(p.heavy_count),
+                                                     (unsigned long long)__popcll(mh) | ((unsigned long long)__popcll(ml) << 32));
+            baseh = (int)(old & 0xffffffffull); basel = (int)(old >> 32);
+        }
+        baseh = __shfl(baseh, 0); basel = __shfl(basel, 0);
         int slot = -1;
-        if (deg[i] > EH_HEAVY_DEG) { slot = atomicAdd(p.heavy_count, 1); p.heavy_nodes[slot] = i; }
-        p.heavy_slot[i] = slot;
+        if (hv) { slot = baseh + __popcll(mh & below); p.heavy_nodes[slot] = i; }
+        if (lg) p.long_slots[basel + __popcll(ml & below)] = slot;
+        if (lane < rows) p.heavy_slot[i] = slot;
     }
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
@@ -788,6 +829,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
                                                     const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
                                                     const float* __restrict__ qbias, int ldq,
                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
+                                                    const int32_t* __restrict__ deg, const int32_t* __restrict__ long_slots,
                                                     float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
@@ -801,7 +843,20 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
     // of ~B/8 graphs (a few MB: L2-resident) instead of all of them.  Affinity only; any placement is correct.
     const int xcd = blockIdx.x & 7, nloc = (gridDim.x + 7 - xcd) >> 3;      // blocks of this XCD
     const int s0 = (int)((int64_t)nheavy * xcd / 8), s1 = (int)((int64_t)nheavy * (xcd + 1) / 8);
-    for (int idx = s0 + (blockIdx.x >> 3); idx < s1; idx += nloc) {
+    // work of this block: first the long rows (blocks are dispatched in index order, so the rows that take
+    // longest start first), then its share of the XCD slice without them
+    const int nlong = counter[1];
+    for (int it = blockIdx.x;; it += gridDim.x) {
+        int idx;
+        if (it < nlong) {
+            idx = long_slots[it];
+        } else {
+            // after its long rows (block-uniform count) the block walks the slice
+            const int first = nlong > (int)blockIdx.x ? (nlong - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+            idx = s0 + (blockIdx.x >> 3) + ((it - (int)blockIdx.x) / (int)gridDim.x - first) * nloc;
+            if (idx >= s1) break;
+            if (deg[heavy_nodes[idx]] > EH_LONG_DEG) continue;
+        }
         const int node = heavy_nodes[idx];
         const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
@@ -1448,12 +1503,13 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    (void)hipMemsetAsync(w.heavy_count, 0, 4, s);
+    (void)hipMemsetAsync(w.heavy_count, 0, 8, s);       // [0] heavy rows, [1] long rows among them
     {
         eh_prep_args pa = {};
         pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
         pa.deg = deg; pa.d0 = d0; pa.flags = flags; pa.idle = idle; pa.h0 = w.hA; pa.part = w.part;
         pa.heavy_count = w.heavy_count; pa.heavy_nodes = w.heavy_nodes; pa.heavy_slot = w.heavy_slot;
+        pa.long_slots = w.long_slots;
         pa.dedupe = h_out ? 0 : 1; pa.crow = w.crow; pa.cwgt = w.cwgt; pa.rep_of = w.rep_of; pa.ccount = w.ccount;
         pa.tile_blocks = tile_blocks;
         EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_step_prepare, dim3(tile_blocks + B), dim3(256), 0, s, *L, pa));
@@ -1501,10 +1557,10 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         }
         const int hb = Nn < 16384 ? Nn : 16384;          // single-wave blocks
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, w.Z)); break;
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
         }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
