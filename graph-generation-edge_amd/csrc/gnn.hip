@@ -1242,10 +1242,15 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     __syncthreads();
     EH_STAMP_AT(2);
 
-    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1); K chunks split over the waves
+    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1).  wave = (column tile ct, K half kh):
+    // the 2 x (HEADS+1) (column tile, 64-deep chunk) products are dealt 5/5/4/4 (HEADS = 8) and only two
+    // partial tiles per output meet in LDS
     {
-        f32x16 acc0 = eh_zero16(), acc1 = eh_zero16();
-        for (int ch = wave; ch < HEADS + 1; ch += 4) {
+        const int ct = wave & 1, kh = wave >> 1;
+        constexpr int NCH = HEADS + 1, SPLIT = (NCH + 1) / 2;
+        const int ch0 = kh ? SPLIT : 0, ch1 = kh ? NCH : SPLIT;
+        f32x16 acc = eh_zero16();
+        for (int ch = ch0; ch < ch1; ++ch) {
             eh_frag af, bf;
             if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
             if (ch < HEADS) {
@@ -1255,31 +1260,23 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             } else {
                 eh_load_frag_lds(af, hp, r, hh);
             }
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, 0, ch, lane);
-            eh_mma64(acc0, af, bf);
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, 1, ch, lane);
-            eh_mma64(acc1, af, bf);
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, ch, lane);
+            eh_mma64(acc, af, bf);
         }
         __syncthreads();                      // every wave is done reading qz
         EH_STAMP_AT(3);
         float* mine = pt + wave * EH_TSZ;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int rr = eh_crow(i, lane);
-            mine[rr * EH_TP + r] = acc0[i];
-            mine[rr * EH_TP + 32 + r] = acc1[i];
-        }
+        for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_TP + r] = acc[i];
         __syncthreads();
         const int row = tid >> 3, c0 = (tid & 7) * 8;
+        const float* p0 = pt + (c0 >> 5) * EH_TSZ + row * EH_TP + (c0 & 31);      // K half 0 of this column tile
         const bool hasnbr = a.deg[nl[row]] > 0;
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(pt + row * EH_TP + c0 + 4 * q4);
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(pt + w * EH_TSZ + row * EH_TP + c0 + 4 * q4);
-                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-            }
+            f32x4 v = *reinterpret_cast<const f32x4*>(p0 + 4 * q4);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p0 + 2 * EH_TSZ + 4 * q4);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int col = c0 + 4 * q4 + e;
