@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #ifndef EH_EXP_LDS_PAD
 #define EH_EXP_LDS_PAD 0          // occupancy experiments only
 #endif
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 64 + EH_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 96 + EH_EXP_LDS_PAD];
     float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
     float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
     float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
@@ -967,6 +967,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [4 waves][8 targets][EH_HEAVY_DEG] neighbour ids
     int* nl = idl + 4 * 8 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
     float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
+    int* dl = nl + 64;                                             // [32] degree of every row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so XCD x gets the
@@ -989,6 +990,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
     const int mydeg = a.deg[mynid];
     const int myhs = a.heavy_slot[mynid];
+    if (tid < 32) dl[tid] = mydeg;                                         // visible after the first barrier
 #ifdef EH_STAMP
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1247,6 +1249,14 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // partial tiles per output meet in LDS
     {
         const int ct = wave & 1, kh = wave >> 1;
+        // epilogue operands requested before the products (after the barriers they would expose an L2 round trip)
+        const int row = tid >> 3, c0 = (tid & 7) * 8;
+        f32x4 ob0[2], ob1[2];
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+            ob0[q4] = *reinterpret_cast<const f32x4*>(a.obias0 + (size_t)g * 64 + c0 + 4 * q4);
+            ob1[q4] = *reinterpret_cast<const f32x4*>(a.obias1 + (size_t)g * 64 + c0 + 4 * q4);
+        }
         constexpr int NCH = HEADS + 1, SPLIT = (NCH + 1) / 2;
         const int ch0 = kh ? SPLIT : 0, ch1 = kh ? NCH : SPLIT;
         f32x16 acc = eh_zero16();
@@ -1269,9 +1279,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_TP + r] = acc[i];
         __syncthreads();
-        const int row = tid >> 3, c0 = (tid & 7) * 8;
         const float* p0 = pt + (c0 >> 5) * EH_TSZ + row * EH_TP + (c0 & 31);      // K half 0 of this column tile
-        const bool hasnbr = a.deg[nl[row]] > 0;
+        const bool hasnbr = dl[row] > 0;
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(p0 + 4 * q4);
@@ -1279,9 +1288,8 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int col = c0 + 4 * q4 + e;
-                float x = v[e] + a.obias0[(size_t)g * 64 + col];
-                if (hasnbr) x += a.obias1[(size_t)g * 64 + col];
+                float x = v[e] + ob0[q4][e];
+                if (hasnbr) x += ob1[q4][e];
                 v[e] = eh_silu_fast(x);
             }
             *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0 + 4 * q4) = v;
@@ -1298,13 +1306,16 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         eh_load_frag_lds(am, mt, r, hh);
         eh_load_frag_lds(ah, hp, r, hh);
         f32x16 g0 = eh_zero16(), g1 = eh_zero16();
+        // gate biases requested before the products: part 1 -> (b_iz + b_hz, b_hn), part 0 -> (b_ir + b_hr, b_in)
+        const float bA = a.b_ih[(part ? 64 : 0) + col] + a.b_hh[(part ? 64 : 0) + col];
+        const float bB = part ? a.b_hh[128 + col] : a.b_ih[128 + col];
         float* xz = xg + (ct * 2 + 0) * 1024;
         float* xh = xg + (ct * 2 + 1) * 1024;
         if (part == 1) {
             eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane); eh_mma64(g0, am, bf);
             eh_load_frag_packed(bf, a.w_hh, 1, 2 + ct, 0, lane); eh_mma64(g0, ah, bf);
             eh_load_frag_packed(bf, a.w_hh, 1, 4 + ct, 0, lane); eh_mma64(g1, ah, bf);
-            const float biz = a.b_ih[64 + col] + a.b_hh[64 + col], bhn = a.b_hh[128 + col];
+            const float biz = bA, bhn = bB;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + biz)));
@@ -1317,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
         __syncthreads();
         if (part == 0) {
-            const float bir = a.b_ih[col] + a.b_hh[col], bin = a.b_ih[128 + col];
+            const float bir = bA, bin = bB;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 int rr = eh_crow(i, lane);
