@@ -88,6 +88,10 @@ struct eh_gemm_desc {
     int64_t M;                          // rows when tile_row0 == null
     const int32_t* m_dev;               // optional device-side row count overriding M
     int prof_id;                        // kernel class for the optional event timer (prof.h)
+    // training extras, honoured by the LDS-staged kernel only (k_gemm): Y += result instead of Y = result
+    // (fan-in of gradients), and a second output Y2 = SiLU(Y) so the pre-activation stays for the backward
+    int accum;
+    float* Y2;
 };
 
 // Packed-weight variant: W in fragment order, no LDS, no barriers; every wave streams its fragments

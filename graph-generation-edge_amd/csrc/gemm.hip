@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
                     float v = acc[j][i] + add0;
                     if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
                     if (d.act == 1) v = eh_silu(v);
+                    if (d.accum) v += d.Y[grow * d.ldy + col];
                     d.Y[grow * d.ldy + col] = v;
+                    if (d.Y2) d.Y2[grow * d.ldy + col] = eh_silu(v);
                 }
             }
         }
@@ -92,6 +94,7 @@ void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nac
 
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
     if (!d.A || !d.W || !d.Y) return EDGEHIP_ERR_ARG;
+    if (d.w_packed && (d.accum || d.Y2)) return EDGEHIP_ERR_UNSUPPORTED;
     if (d.K <= 0 || d.N <= 0 || (d.K & 63) || (d.N & 31)) return EDGEHIP_ERR_UNSUPPORTED;
     if (d.A2 ? ((d.K1 & 63) || d.K1 <= 0 || d.K1 >= d.K) : (d.K1 != d.K)) return EDGEHIP_ERR_ARG;
     if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;

@@ -165,41 +165,53 @@ __global__ void k_tr_assemble_fwd(int Nn, const int32_t* node_graph, const float
     out[idx] = v;
 }
 
-// column sums of src[rows of graph g][col0 .. col0+64) into out[g][64] (scaled); one block per graph
+// column sums of src[rows of graph g][col0 .. col0+64) ADDED into out[g][64] (scaled): blockIdx.y = graph,
+// blockIdx.x = chunk of TR_SEG_ROWS rows, one float atomic per (block, column); `out` is zero-filled (or holds
+// the value to accumulate onto) before the launch.  One block per graph left 4 blocks on 256 CUs (70 us).
+#define TR_SEG_ROWS 128
 __global__ __launch_bounds__(256) void k_tr_segment_sum(const int32_t* node_ptr, const float* src, int ld, int col0,
                                                         const float* add, int mean, float* out) {
     __shared__ float part[4][64];
-    const int g = blockIdx.x, c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int g = blockIdx.y, c = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int i0 = node_ptr[g], i1 = node_ptr[g + 1];
+    const int a = i0 + (int)blockIdx.x * TR_SEG_ROWS;
+    if (a >= i1 && blockIdx.x != 0) return;                 // chunk 0 still delivers `add` for an empty graph
+    const int b = a + TR_SEG_ROWS < i1 ? a + TR_SEG_ROWS : i1;
     float s = 0.f;
-    for (int i = i0 + r; i < i1; i += 4) s += src[(int64_t)i * ld + col0 + c];
+    for (int i = a + r; i < b; i += 4) s += src[(int64_t)i * ld + col0 + c];
     part[r][c] = s;
     __syncthreads();
     if (r == 0) {
         s = part[0][c] + part[1][c] + part[2][c] + part[3][c];
         if (mean) s = (i1 > i0) ? s / (float)(i1 - i0) : 0.f;
-        if (add) s += add[g * 64 + c];
-        out[g * 64 + c] = s;
+        if (add && blockIdx.x == 0) s += add[g * 64 + c];
+        atomicAdd(out + g * 64 + c, s);
     }
 }
+static inline dim3 tr_seg_grid(const edgehip_layout* L) {
+    int chunks = (L->max_nodes + TR_SEG_ROWS - 1) / TR_SEG_ROWS;
+    return dim3(chunks < 1 ? 1 : chunks, L->num_graphs);
+}
 
-// dst[i][0..ncol) = src[i][col0 .. col0+ncol)   (strided slice -> contiguous)
-__global__ void k_tr_slice(int64_t M, const float* src, int ld, int col0, int ncol, float* dst) {
+// dst[i][0..ncol) (+)= src[i][col0 .. col0+ncol)   (strided slice -> contiguous)
+__global__ void k_tr_slice(int64_t M, const float* src, int ld, int col0, int ncol, float* dst, int acc) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * ncol) return;
     int64_t i = idx / ncol;
     int c = (int)(idx % ncol);
-    dst[idx] = src[i * ld + col0 + c];
+    float v = src[i * ld + col0 + c];
+    dst[idx] = acc ? dst[idx] + v : v;
 }
 
-// dx[i][c] = dout[g(i)][c] / n_g
+// dx[i][c] (+)= dout[g(i)][c] / n_g
 __global__ void k_tr_segment_mean_bwd(int Nn, const int32_t* node_graph, const int32_t* node_ptr, const float* dout,
-                                      float* dx) {
+                                      float* dx, int acc) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Nn * 64) return;
     int i = idx >> 6, c = idx & 63;
     int g = node_graph[i];
-    dx[idx] = dout[g * 64 + c] / (float)(node_ptr[g + 1] - node_ptr[g]);
+    float v = dout[g * 64 + c] / (float)(node_ptr[g + 1] - node_ptr[g]);
+    dx[idx] = acc ? dx[idx] + v : v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,41 +234,110 @@ __device__ static inline tr_row tr_row_of(const edgehip_layout& L, const uint32_
     return r;
 }
 
-template <int H>
-__global__ __launch_bounds__(64 * H) void k_tr_attn_fwd(edgehip_layout L, const uint32_t* adj, const float* Q, const float* K,
-                                                        const float* V, const float* skip, float* out, float* O, float* lse) {
-    __shared__ float red[H][64];
-    const int i = blockIdx.x;
-    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = threadIdx.x & 63;
-    const tr_row row = tr_row_of(L, adj, i);
-    const int HD = H * 64;
-    const float q = Q[(int64_t)i * HD + h * 64 + c];
-    float m = -INFINITY, l = 0.f, acc = 0.f;
-    for (int w = 0; w < row.words; ++w) {
-        uint32_t bits = row.bits[w];
+// Neighbour walk shared by the three attention kernels.  The bit row is decoded 64 words at a time into an
+// LDS list by wave 0 (popcount + wave prefix sum); every wave (= head) then visits FOUR neighbours per step:
+// lane = (slot 0..3, 4 channels), the 64-channel dot products are 4 adds + 4 exchanges inside a 16-lane
+// group, and the per-slot partial results meet at the end (the one-neighbour-per-step form spent its time
+// in 64-lane reductions: 140 us per launch on 4 polblogs graphs).
+#define TR_LIST 2048
+__device__ static inline int tr_decode_chunk(const tr_row& row, int w0, int* list, int* cnt) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int w = w0 + lane;
+        uint32_t bits = (w < row.words) ? row.bits[w] : 0u;
+        const int pc = __popc(bits);
+        int pre = pc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += t;
+        }
+        int off = pre - pc;
         while (bits) {
             int b = __builtin_ctz(bits);
             bits &= bits - 1;
-            int64_t j = row.node0 + w * 32 + b;
-            float kj = K[j * HD + h * 64 + c], vj = V[j * HD + h * 64 + c];
-            float s = tr_wave_sum(q * kj) * 0.125f;
-            float mn = fmaxf(m, s);
-            float sc = expf(m - mn), p = expf(s - mn);
-            l = l * sc + p;
-            acc = acc * sc + p * vj;
-            m = mn;
+            list[off++] = row.node0 + w * 32 + b;
         }
+        if (lane == 63) *cnt = pre;
     }
-    float o = l > 0.f ? acc / (l + 1e-16f) : 0.f;          // pyg softmax: w / (sum + 1e-16)
-    O[(int64_t)i * HD + h * 64 + c] = o;
-    if (c == 0) lse[(int64_t)i * H + h] = l > 0.f ? m + logf(l + 1e-16f) : 0.f;
-    red[h][c] = o;
+    __syncthreads();
+    return *cnt;
+}
+__device__ static inline float tr_sum16(float v) {          // sum over the 16 lanes of a slot, in every lane
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ static inline float tr_dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+__device__ static inline f32x4 tr_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ static inline f32x4 tr_slots_sum(f32x4 v) {       // sum of the four slots, in every lane
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v[c] += __shfl_xor(v[c], 16, 64);
+        v[c] += __shfl_xor(v[c], 32, 64);
+    }
+    return v;
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * H) void k_tr_attn_fwd(edgehip_layout L, const uint32_t* adj, const float* Q, const float* K,
+                                                        const float* V, const float* skip, float* out, float* O, float* lse) {
+    __shared__ int list[TR_LIST];
+    __shared__ int cnt;
+    __shared__ float red[H][64];
+    const int i = blockIdx.x;
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int slot = lane >> 4, c4 = (lane & 15) * 4;
+    const tr_row row = tr_row_of(L, adj, i);
+    const int HD = H * 64;
+    const f32x4 q = tr_ld4(Q + (int64_t)i * HD + h * 64 + c4);
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < row.words; w0 += 64) {
+        const int n = tr_decode_chunk(row, w0, list, &cnt);
+        for (int e0 = 0; e0 < n; e0 += 4) {
+            const bool ok = e0 + slot < n;
+            const int64_t j = list[ok ? e0 + slot : e0];
+            const f32x4 kj = tr_ld4(K + j * HD + h * 64 + c4), vj = tr_ld4(V + j * HD + h * 64 + c4);
+            const float sc = tr_sum16(tr_dot4(q, kj)) * 0.125f;
+            if (ok) {
+                const float mn = fmaxf(m, sc);
+                const float r = expf(m - mn), pr = expf(sc - mn);
+                l = l * r + pr;
+                acc = acc * r + pr * vj;
+                m = mn;
+            }
+        }
+        __syncthreads();
+    }
+    // the four slots meet
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+        f32x4 a2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a2[c] = __shfl_xor(acc[c], o, 64);
+        const float mn = fmaxf(m, m2);
+        const float r1 = l > 0.f ? expf(m - mn) : 0.f, r2 = l2 > 0.f ? expf(m2 - mn) : 0.f;
+        l = l * r1 + l2 * r2;
+        acc = acc * r1 + a2 * r2;
+        m = mn;
+    }
+    f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+    if (l > 0.f) o4 = acc * (1.0f / (l + 1e-16f));            // pyg softmax: w / (sum + 1e-16)
+    if (slot == 0) {
+        *reinterpret_cast<f32x4*>(O + (int64_t)i * HD + h * 64 + c4) = o4;
+        *reinterpret_cast<f32x4*>(&red[h][c4]) = o4;
+    }
+    if (lane == 0) lse[(int64_t)i * H + h] = l > 0.f ? m + logf(l + 1e-16f) : 0.f;
     __syncthreads();
     if (h == 0) {
-        float s = 0.f;
+        float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < H; ++k) s += red[k][c];
-        out[(int64_t)i * 64 + c] = s * (1.0f / H) + skip[(int64_t)i * 64 + c];
+        for (int k = 0; k < H; ++k) sum += red[k][lane];
+        out[(int64_t)i * 64 + lane] = sum * (1.0f / H) + skip[(int64_t)i * 64 + lane];
     }
 }
 
@@ -265,30 +346,33 @@ template <int H>
 __global__ __launch_bounds__(64 * H) void k_tr_attn_bwd_q(edgehip_layout L, const uint32_t* adj, const float* Q, const float* K,
                                                           const float* V, const float* O, const float* lse,
                                                           const float* dout, float* Dbuf, float* dQ) {
+    __shared__ int list[TR_LIST];
+    __shared__ int cnt;
     const int i = blockIdx.x;
-    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int slot = lane >> 4, c4 = (lane & 15) * 4;
     const tr_row row = tr_row_of(L, adj, i);
     const int HD = H * 64;
-    const float q = Q[(int64_t)i * HD + h * 64 + c];
-    const float go = dout[(int64_t)i * 64 + c] * (1.0f / H);
-    const float D = tr_wave_sum(go * O[(int64_t)i * HD + h * 64 + c]);
+    const f32x4 q = tr_ld4(Q + (int64_t)i * HD + h * 64 + c4);
+    const f32x4 go = tr_ld4(dout + (int64_t)i * 64 + c4) * (1.0f / H);
+    const float D = tr_sum16(tr_dot4(go, tr_ld4(O + (int64_t)i * HD + h * 64 + c4)));
     const float ls = lse[(int64_t)i * H + h];
-    if (c == 0) Dbuf[(int64_t)i * H + h] = D;
-    float dq = 0.f;
-    for (int w = 0; w < row.words; ++w) {
-        uint32_t bits = row.bits[w];
-        while (bits) {
-            int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            int64_t j = row.node0 + w * 32 + b;
-            float kj = K[j * HD + h * 64 + c], vj = V[j * HD + h * 64 + c];
-            float s = tr_wave_sum(q * kj) * 0.125f;
-            float a = expf(s - ls);
-            float dov = tr_wave_sum(go * vj);
-            dq += a * (dov - D) * kj * 0.125f;
+    if (lane == 0) Dbuf[(int64_t)i * H + h] = D;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < row.words; w0 += 64) {
+        const int n = tr_decode_chunk(row, w0, list, &cnt);
+        for (int e0 = 0; e0 < n; e0 += 4) {
+            const bool ok = e0 + slot < n;
+            const int64_t j = list[ok ? e0 + slot : e0];
+            const f32x4 kj = tr_ld4(K + j * HD + h * 64 + c4), vj = tr_ld4(V + j * HD + h * 64 + c4);
+            const float sc = tr_sum16(tr_dot4(q, kj)) * 0.125f;
+            const float dov = tr_sum16(tr_dot4(go, vj));
+            if (ok) dq += (expf(sc - ls) * (dov - D) * 0.125f) * kj;
         }
+        __syncthreads();
     }
-    dQ[(int64_t)i * HD + h * 64 + c] = dq;
+    dq = tr_slots_sum(dq);
+    if (slot == 0) *reinterpret_cast<f32x4*>(dQ + (int64_t)i * HD + h * 64 + c4) = dq;
 }
 
 // dK, dV of node j: the adjacency is symmetric, so the targets that attend to j are row j's bits
@@ -296,29 +380,38 @@ template <int H>
 __global__ __launch_bounds__(64 * H) void k_tr_attn_bwd_kv(edgehip_layout L, const uint32_t* adj, const float* Q, const float* K,
                                                            const float* V, const float* lse, const float* Dbuf,
                                                            const float* dout, float* dK, float* dV) {
+    __shared__ int list[TR_LIST];
+    __shared__ int cnt;
     const int j = blockIdx.x;
-    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int slot = lane >> 4, c4 = (lane & 15) * 4;
     const tr_row row = tr_row_of(L, adj, j);
     const int HD = H * 64;
-    const float kj = K[(int64_t)j * HD + h * 64 + c], vj = V[(int64_t)j * HD + h * 64 + c];
-    float dk = 0.f, dv = 0.f;
-    for (int w = 0; w < row.words; ++w) {
-        uint32_t bits = row.bits[w];
-        while (bits) {
-            int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            int64_t i = row.node0 + w * 32 + b;
-            float qi = Q[i * HD + h * 64 + c];
-            float go = dout[i * 64 + c] * (1.0f / H);
-            float s = tr_wave_sum(qi * kj) * 0.125f;
-            float a = expf(s - lse[i * H + h]);
-            float dov = tr_wave_sum(go * vj);
-            dk += a * (dov - Dbuf[i * H + h]) * qi * 0.125f;
-            dv += a * go;
+    const f32x4 kj = tr_ld4(K + (int64_t)j * HD + h * 64 + c4), vj = tr_ld4(V + (int64_t)j * HD + h * 64 + c4);
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < row.words; w0 += 64) {
+        const int n = tr_decode_chunk(row, w0, list, &cnt);
+        for (int e0 = 0; e0 < n; e0 += 4) {
+            const bool ok = e0 + slot < n;
+            const int64_t i = list[ok ? e0 + slot : e0];
+            const f32x4 qi = tr_ld4(Q + i * HD + h * 64 + c4);
+            const f32x4 go = tr_ld4(dout + i * 64 + c4) * (1.0f / H);
+            const float sc = tr_sum16(tr_dot4(qi, kj)) * 0.125f;
+            const float dov = tr_sum16(tr_dot4(go, vj));
+            if (ok) {
+                const float a = expf(sc - lse[i * H + h]);
+                dk += (a * (dov - Dbuf[i * H + h]) * 0.125f) * qi;
+                dv += a * go;
+            }
         }
+        __syncthreads();
     }
-    dK[(int64_t)j * HD + h * 64 + c] = dk;
-    dV[(int64_t)j * HD + h * 64 + c] = dv;
+    dk = tr_slots_sum(dk);
+    dv = tr_slots_sum(dv);
+    if (slot == 0) {
+        *reinterpret_cast<f32x4*>(dK + (int64_t)j * HD + h * 64 + c4) = dk;
+        *reinterpret_cast<f32x4*>(dV + (int64_t)j * HD + h * 64 + c4) = dv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,22 +492,34 @@ __global__ void k_tr_pair_targets(edgehip_layout L, const uint32_t* adj_tm1, int
 // I. last linear (64 -> 2) + log_softmax + cross-entropy, one wave per pair
 //    (final_out.4 layers.py:381; _compute_MC_KL_joint diffusion_binomial_active.py:157-181)
 // ------------------------------------------------------------------------------------------------
+// a wave owns TR_CE_CHUNK consecutive pairs (pairs are graph-major): it keeps the running sum of the current graph
+// and adds it with ONE atomic when the graph changes (one atomic per pair serialised on B addresses: 170 us)
+#define TR_CE_CHUNK 32
 __global__ __launch_bounds__(256) void k_tr_ce_fwd(int64_t A, const float* e2, const float* W4, const float* b4,
                                                    const uint8_t* tgt, const int32_t* pair_graph, float* logits,
                                                    float* ce_graph) {
-    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TR_CE_CHUNK;
     const int c = threadIdx.x & 63;
-    if (k >= A) return;
-    float x = e2[k * 64 + c];
-    float l0 = tr_wave_sum(x * W4[c]) + b4[0];
-    float l1 = tr_wave_sum(x * W4[64 + c]) + b4[1];
-    if (c == 0) {
-        logits[k * 2] = l0; logits[k * 2 + 1] = l1;
+    if (k0 >= A) return;
+    const int64_t k1 = k0 + TR_CE_CHUNK < A ? k0 + TR_CE_CHUNK : A;
+    const float w0 = W4[c], w1 = W4[64 + c], bb0 = b4[0], bb1 = b4[1];
+    int gcur = pair_graph[k0];
+    float sum = 0.f;
+    for (int64_t k = k0; k < k1; ++k) {
+        float x = e2[k * 64 + c];
+        float l0 = tr_wave_sum(x * w0) + bb0;
+        float l1 = tr_wave_sum(x * w1) + bb1;
+        int g = pair_graph[k];
+        if (g != gcur) {
+            if (c == 0) atomicAdd(ce_graph + gcur, sum);
+            gcur = g; sum = 0.f;
+        }
         float m = fmaxf(l0, l1);
         float lz = m + logf(expf(l0 - m) + expf(l1 - m));
-        float ce = -((tgt[k] ? l1 : l0) - lz);
-        atomicAdd(ce_graph + pair_graph[k], ce);
+        sum += -((tgt[k] ? l1 : l0) - lz);
+        if (c == 0) { logits[k * 2] = l0; logits[k * 2 + 1] = l1; }
     }
+    if (c == 0) atomicAdd(ce_graph + gcur, sum);
 }
 
 __global__ __launch_bounds__(256) void k_tr_ce_bwd(int64_t A, const float* e2, const float* W4, const float* b4,
@@ -540,17 +645,21 @@ extern "C" int edgehip_assemble_bwd(const edgehip_layout* L, const float* dout, 
     hipStream_t s = eh_stream(stream);
     const int ld = 64 + Kt;
     int64_t n = (int64_t)L->num_nodes * 64;
-    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_slice, TR_GRID(n, 256), dim3(256), 0, s, (int64_t)L->num_nodes, dout, ld, 0, 64, dh));
-    if (dctx)
-        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_sum, dim3(L->num_graphs), dim3(256), 0, s, L->node_ptr, dout, ld, 0,
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_slice, TR_GRID(n, 256), dim3(256), 0, s, (int64_t)L->num_nodes, dout, ld, 0, 64, dh, 0));
+    if (dctx) {
+        if (hipMemsetAsync(dctx, 0, (size_t)L->num_graphs * 64 * sizeof(float), s) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_sum, tr_seg_grid(L), dim3(256), 0, s, L->node_ptr, dout, ld, 0,
                            (const float*)nullptr, 0, dctx));
-    if (dtail_graph)
-        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_sum, dim3(L->num_graphs), dim3(256), 0, s, L->node_ptr, dout, ld, 64,
+    }
+    if (dtail_graph) {
+        if (hipMemsetAsync(dtail_graph, 0, (size_t)L->num_graphs * 64 * sizeof(float), s) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_sum, tr_seg_grid(L), dim3(256), 0, s, L->node_ptr, dout, ld, 64,
                            (const float*)nullptr, 0, dtail_graph));
+    }
     if (dtail_rows && Kt > 0) {
         int64_t m = (int64_t)L->num_nodes * Kt;
         EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_slice, TR_GRID(m, 256), dim3(256), 0, s, (int64_t)L->num_nodes, dout, ld, 64, Kt,
-                           dtail_rows));
+                           dtail_rows, 0));
     }
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
@@ -559,7 +668,8 @@ extern "C" int edgehip_assemble_bwd(const edgehip_layout* L, const float* dout, 
 extern "C" int edgehip_segment_mean_fwd(const edgehip_layout* L, const float* x, const float* add, float* out, void* stream) {
     EH_CHECK_ARG(L && x && out);
     if (L->num_graphs == 0) return EDGEHIP_OK;
-    EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_segment_sum, dim3(L->num_graphs), dim3(256), 0, eh_stream(stream),
+    if (hipMemsetAsync(out, 0, (size_t)L->num_graphs * 64 * sizeof(float), eh_stream(stream)) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+    EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_segment_sum, tr_seg_grid(L), dim3(256), 0, eh_stream(stream),
                        L->node_ptr, x, 64, 0, add, 1, out));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
@@ -570,7 +680,7 @@ extern "C" int edgehip_segment_mean_bwd(const edgehip_layout* L, const float* do
     if (L->num_nodes == 0) return EDGEHIP_OK;
     int64_t n = (int64_t)L->num_nodes * 64;
     EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_segment_mean_bwd, TR_GRID(n, 256), dim3(256), 0, eh_stream(stream),
-                       L->num_nodes, L->node_graph, L->node_ptr, dout, dx));
+                       L->num_nodes, L->node_graph, L->node_ptr, dout, dx, 0));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -674,7 +784,7 @@ extern "C" int edgehip_edge_ce_fwd(const float* e2, const float* W4, const float
                                    const int32_t* pair_graph, int64_t A, float* logits, float* ce_graph, void* stream) {
     EH_CHECK_ARG(e2 && W4 && b4 && tgt && pair_graph && logits && ce_graph && A >= 0);
     if (A == 0) return EDGEHIP_OK;
-    EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_ce_fwd, TR_GRID(A, 4), dim3(256), 0, eh_stream(stream),
+    EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_ce_fwd, TR_GRID(A, 4 * TR_CE_CHUNK), dim3(256), 0, eh_stream(stream),
                        A, e2, W4, b4, tgt, pair_graph, logits, ce_graph));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
@@ -691,4 +801,351 @@ extern "C" int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float
                        A, e2, W4, b4, tgt, pair_graph, gkl, de2, dW4, db4));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
+}
+
+// ================================================================================================
+// J. The whole differentiable network in two calls.
+//    edgehip_train_forward / edgehip_train_backward queue the SAME ops as above, in the order of
+//    TGNN_degree_guided.forward (layers/layers.py:315-383), from one host call each: ~190 / ~330 launches are
+//    issued back to back by the library instead of one Python autograd node per op (which bounded the step
+//    at ~25 us per op on the host).  Everything the backward needs stays in the caller's workspace between
+//    the two calls; gradients are ADDED into the buffers of `G` (a parameter struct whose pointers address
+//    gradient storage), so the caller zero-fills one flat gradient buffer per step and nothing is copied.
+// ================================================================================================
+#define TR_RC(x) do { int rc__ = (x); if (rc__ != EDGEHIP_OK) return rc__; } while (0)
+#define TR_HIP(x) do { if ((x) != hipSuccess) return EDGEHIP_ERR_LAUNCH; } while (0)
+
+struct tr_bump {
+    float* base; size_t off;
+    float* take(size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return base ? base + o : nullptr; }
+};
+
+struct tr_plan {
+    // saved by the forward
+    float *X0, *a0, *hs[EDGEHIP_MAX_LAYERS + 1];
+    float *pe, *m1, *m1s, *m2, *mt;
+    float *gin[EDGEHIP_MAX_LAYERS + 1], *g1[EDGEHIP_MAX_LAYERS + 1], *g1s[EDGEHIP_MAX_LAYERS + 1], *cx[EDGEHIP_MAX_LAYERS + 1];
+    float *tl[EDGEHIP_MAX_LAYERS], *x[EDGEHIP_MAX_LAYERS], *q[EDGEHIP_MAX_LAYERS], *k[EDGEHIP_MAX_LAYERS], *v[EDGEHIP_MAX_LAYERS];
+    float *sk[EDGEHIP_MAX_LAYERS], *O[EDGEHIP_MAX_LAYERS], *lse[EDGEHIP_MAX_LAYERS], *conv[EDGEHIP_MAX_LAYERS], *xs[EDGEHIP_MAX_LAYERS];
+    float *gi[EDGEHIP_MAX_LAYERS], *gh[EDGEHIP_MAX_LAYERS], *cin[EDGEHIP_MAX_LAYERS], *c1[EDGEHIP_MAX_LAYERS], *c1s[EDGEHIP_MAX_LAYERS];
+    float *nctx[EDGEHIP_MAX_LAYERS];
+    float *zin, *n1, *n1s, *n2, *n2s, *z, *e, *f1, *f1s, *f2, *f2s;
+    // backward temporaries
+    float *wt_node_in, *wt_mlp2, *wt_g0, *wt_g2, *wt_c0, *wt_c2, *wt_ih, *wt_hh, *wt_time[EDGEHIP_MAX_LAYERS];
+    float *wt_q[EDGEHIP_MAX_LAYERS], *wt_k[EDGEHIP_MAX_LAYERS], *wt_v[EDGEHIP_MAX_LAYERS], *wt_sk[EDGEHIP_MAX_LAYERS];
+    float *wt_no0, *wt_no2, *wt_no4, *wt_f0, *wt_f2;
+    float *dA0, *dA1, *big0, *big1, *big2, *dx, *dh, *dh2, *dconv, *dX0, *Dbuf;
+    float *dcx, *ds, *dg1, *dtl, *dmt, *dm1;
+    size_t floats;
+};
+
+static void tr_make_plan(tr_plan& p, const edgehip_layout* L, const edgehip_gnn_params* P, int64_t A, float* base) {
+    tr_bump b{base, 0};
+    const size_t Nn = L->num_nodes, B = L->num_graphs, nl = P->num_layers;
+    int hmax = 1;
+    for (size_t i = 0; i < nl; ++i) hmax = P->heads[i] > hmax ? P->heads[i] : hmax;
+    p.X0 = b.take(Nn * 192); p.a0 = b.take(Nn * 64);
+    for (size_t i = 0; i <= nl; ++i) p.hs[i] = b.take(Nn * 64);
+    p.pe = b.take(B * 64); p.m1 = b.take(B * 256); p.m1s = b.take(B * 256); p.m2 = b.take(B * 64); p.mt = b.take(B * 64);
+    for (size_t i = 0; i <= nl; ++i) {
+        p.gin[i] = b.take(B * 64); p.g1[i] = b.take(B * 256); p.g1s[i] = b.take(B * 256); p.cx[i] = b.take(B * 64);
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        const size_t hd = (size_t)P->heads[i] * 64;
+        p.tl[i] = b.take(B * 64); p.x[i] = b.take(Nn * 128);
+        p.q[i] = b.take(Nn * hd); p.k[i] = b.take(Nn * hd); p.v[i] = b.take(Nn * hd); p.sk[i] = b.take(Nn * 64);
+        p.O[i] = b.take(Nn * hd); p.lse[i] = b.take(Nn * P->heads[i]); p.conv[i] = b.take(Nn * 64); p.xs[i] = b.take(Nn * 64);
+        p.gi[i] = b.take(Nn * 192); p.gh[i] = b.take(Nn * 192); p.cin[i] = b.take(Nn * 128);
+        p.c1[i] = b.take(Nn * 256); p.c1s[i] = b.take(Nn * 256); p.nctx[i] = b.take(Nn * 64);
+    }
+    p.zin = b.take(Nn * 256); p.n1 = b.take(Nn * 128); p.n1s = b.take(Nn * 128); p.n2 = b.take(Nn * 128); p.n2s = b.take(Nn * 128);
+    p.z = b.take(Nn * 128);
+    p.e = b.take(A * 128); p.f1 = b.take(A * 128); p.f1s = b.take(A * 128); p.f2 = b.take(A * 64); p.f2s = b.take(A * 64);
+    p.wt_node_in = b.take(64 * 192); p.wt_mlp2 = b.take(64 * 256); p.wt_g0 = b.take(256 * 64); p.wt_g2 = b.take(64 * 256);
+    p.wt_c0 = b.take(256 * 128); p.wt_c2 = b.take(64 * 256); p.wt_ih = b.take(192 * 64); p.wt_hh = b.take(192 * 64);
+    for (size_t i = 0; i < nl; ++i) {
+        const size_t hd = (size_t)P->heads[i] * 64;
+        p.wt_time[i] = b.take(64 * 64); p.wt_q[i] = b.take(hd * 128); p.wt_k[i] = b.take(hd * 128); p.wt_v[i] = b.take(hd * 128);
+        p.wt_sk[i] = b.take(64 * 128);
+    }
+    p.wt_no0 = b.take(128 * 256); p.wt_no2 = b.take(128 * 128); p.wt_no4 = b.take(128 * 128); p.wt_f0 = b.take(128 * 128);
+    p.wt_f2 = b.take(64 * 128);
+    const size_t bigw = (size_t)(hmax * 64 > 256 ? hmax * 64 : 256);
+    p.dA0 = b.take(A * 128); p.dA1 = b.take(A * 128);
+    p.big0 = b.take(Nn * bigw); p.big1 = b.take(Nn * bigw); p.big2 = b.take(Nn * bigw);
+    p.dx = b.take(Nn * 128); p.dh = b.take(Nn * 64); p.dh2 = b.take(Nn * 64); p.dconv = b.take(Nn * 64); p.dX0 = b.take(Nn * 192);
+    p.Dbuf = b.take(Nn * hmax);
+    p.dcx = b.take(B * 64); p.ds = b.take(B * 64); p.dg1 = b.take(B * 256); p.dtl = b.take(B * 64); p.dmt = b.take(B * 64);
+    p.dm1 = b.take(B * 256);
+    p.floats = b.off;
+}
+
+static int tr_check_net(const edgehip_gnn_params* P) {
+    if (!P || P->dim != 64 || P->num_layers < 1 || P->num_layers > EDGEHIP_MAX_LAYERS || P->max_degree <= 0) return EDGEHIP_ERR_UNSUPPORTED;
+    for (int i = 0; i < P->num_layers; ++i) {
+        int h = P->heads[i];
+        if (h != 1 && h != 2 && h != 4 && h != 8) return EDGEHIP_ERR_UNSUPPORTED;
+    }
+    return EDGEHIP_OK;
+}
+
+extern "C" size_t edgehip_train_workspace_bytes(const edgehip_layout* L, const edgehip_gnn_params* P, int64_t A) {
+    if (!L || tr_check_net(P) != EDGEHIP_OK || A < 0) return 0;
+    tr_plan p;
+    tr_make_plan(p, L, P, A, nullptr);
+    return p.floats * sizeof(float) + 256;
+}
+
+static float* tr_ws_base(void* ws) { return reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255); }
+
+__global__ void k_tr_pos_gather(int B, const int32_t* t_graph, const float* pos_emb, int T, float* pe) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 64) return;
+    int g = idx >> 6, c = idx & 63;
+    int t = t_graph[g];
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    pe[idx] = pos_emb[(int64_t)t * 64 + c];
+}
+
+// Y = X W^T + b (pre-activation kept), optional Y2 = SiLU(Y)
+static int tr_lin(const float* X, int64_t M, int K, const float* W, const float* b, int N, float* Y, float* Y2, hipStream_t s) {
+    if (M == 0) return EDGEHIP_OK;
+    eh_gemm_desc d = {};
+    d.A = X; d.lda = K; d.K1 = K; d.W = W; d.K = K; d.N = N; d.bias = b; d.Y = Y; d.ldy = N; d.M = M; d.prof_id = EH_K_TRAIN;
+    d.Y2 = Y2;
+    return eh_launch_gemm(d, s);
+}
+// dX[M,K] (+)= dY[M,N] W[N,K], WT = W^T as [K,N]
+static int tr_lin_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum, hipStream_t s) {
+    if (M == 0) return EDGEHIP_OK;
+    eh_gemm_desc d = {};
+    d.A = dY; d.lda = N; d.K1 = N; d.W = WT; d.K = N; d.N = K; d.Y = dX; d.ldy = K; d.M = M; d.prof_id = EH_K_TRAIN;
+    d.accum = accum;
+    return eh_launch_gemm(d, s);
+}
+static int tr_transpose(const float* W, int N, int K, float* WT, hipStream_t s) {
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, W, N, K, WT));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+static int tr_slice(int64_t M, const float* src, int ld, int col0, int ncol, float* dst, int acc, hipStream_t s) {
+    if (M == 0) return EDGEHIP_OK;
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_slice, TR_GRID(M * ncol, 256), dim3(256), 0, s, M, src, ld, col0, ncol, dst, acc));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+// out[B,64] (+)= per-graph column sums of src[:, col0:col0+64]
+static int tr_segsum(const edgehip_layout* L, const float* src, int ld, int col0, float* out, int acc, hipStream_t s) {
+    if (L->num_graphs == 0) return EDGEHIP_OK;
+    if (!acc) TR_HIP(hipMemsetAsync(out, 0, (size_t)L->num_graphs * 64 * sizeof(float), s));
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_sum, tr_seg_grid(L), dim3(256), 0, s, L->node_ptr, src, ld, col0,
+                       (const float*)nullptr, 0, out));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+static int tr_segmean_bwd(const edgehip_layout* L, const float* dout, float* dx, int acc, hipStream_t s) {
+    if (L->num_nodes == 0) return EDGEHIP_OK;
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_segment_mean_bwd, TR_GRID((int64_t)L->num_nodes * 64, 256), dim3(256), 0, s,
+                       L->num_nodes, L->node_graph, L->node_ptr, dout, dx, acc));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
+// global_mlp(gin) -> cx   (layers.py:343,368)
+static int tr_global_fwd(const edgehip_gnn_params* P, const tr_plan& p, int j, int64_t B, hipStream_t s) {
+    TR_RC(tr_lin(p.gin[j], B, 64, P->global_w0, P->global_b0, 256, p.g1[j], p.g1s[j], s));
+    return tr_lin(p.g1s[j], B, 256, P->global_w2, P->global_b2, 64, p.cx[j], nullptr, s);
+}
+// d cx[j] (in p.dcx) -> d gin[j] (into p.ds); weight gradients accumulate
+static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, int64_t B, float* dcx, float* ds, void* st) {
+    hipStream_t s = eh_stream(st);
+    TR_RC(edgehip_linear_bwd_weight(dcx, p.g1s[j], B, 64, 256, (float*)G->global_w2, (float*)G->global_b2, st));
+    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.g1[j], p.dg1, B * 256, p.dg1, st));
+    TR_RC(edgehip_linear_bwd_weight(p.dg1, p.gin[j], B, 256, 64, (float*)G->global_w0, (float*)G->global_b0, st));
+    return tr_lin_dx(p.dg1, B, 256, p.wt_g0, 64, ds, 0, s);
+}
+
+extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                     const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
+                                     const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
+                                     const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    EH_CHECK_ARG(L && P && adj_t && deg_t && d0 && flags && t_graph && ce_graph && ws && A >= 0);
+    EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph && logits));
+    TR_RC(tr_check_net(P));
+    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A)) return EDGEHIP_ERR_WORKSPACE;
+    hipStream_t s = eh_stream(stream);
+    const int64_t Nn = L->num_nodes, B = L->num_graphs;
+    const int nl = P->num_layers;
+    TR_HIP(hipMemsetAsync(ce_graph, 0, (size_t)B * sizeof(float), s));
+    if (Nn == 0 || B == 0) return EDGEHIP_OK;
+    tr_plan p;
+    tr_make_plan(p, L, P, A, tr_ws_base(ws));
+    // input embeddings, node_in (layers.py:326-336)
+    TR_RC(edgehip_train_embed_fwd(L, deg_t, d0, flags, P->max_degree, P->embedding_t_w, P->embedding_t_b, P->embedding_0_w,
+                                  P->embedding_0_b, P->embedding_sel_w, p.X0, stream));
+    TR_RC(tr_lin(p.X0, Nn, 192, P->node_in_w, P->node_in_b, 64, p.a0, p.hs[0], s));
+    // time embedding: Mish(mlp(sinusoid))  (layers.py:338-339)
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_pos_gather, TR_GRID(B * 64, 256), dim3(256), 0, s, (int)B, t_graph, P->pos_emb,
+                       P->num_steps, p.pe));
+    EH_LAUNCH_CHECK();
+    TR_RC(tr_lin(p.pe, B, 64, P->mlp_w0, P->mlp_b0, 256, p.m1, p.m1s, s));
+    TR_RC(tr_lin(p.m1s, B, 256, P->mlp_w2, P->mlp_b2, 64, p.m2, nullptr, s));
+    TR_RC(edgehip_act_fwd(2, p.m2, B * 64, p.mt, stream));
+    // first context (layers.py:342-343)
+    TR_RC(edgehip_segment_mean_fwd(L, p.hs[0], nullptr, p.gin[0], stream));
+    TR_RC(tr_global_fwd(P, p, 0, B, s));
+    for (int i = 0; i < nl; ++i) {
+        const int h = P->heads[i], hd = h * 64;
+        TR_RC(tr_lin(p.mt, B, 64, P->time_w[i], P->time_b[i], 64, p.tl[i], nullptr, s));
+        TR_RC(edgehip_assemble_fwd(L, p.hs[i], i > 0 ? p.cx[i] : nullptr, p.tl[i], nullptr, 64, p.x[i], stream));
+        TR_RC(tr_lin(p.x[i], Nn, 128, P->query_w[i], P->query_b[i], hd, p.q[i], nullptr, s));
+        TR_RC(tr_lin(p.x[i], Nn, 128, P->key_w[i], P->key_b[i], hd, p.k[i], nullptr, s));
+        TR_RC(tr_lin(p.x[i], Nn, 128, P->value_w[i], P->value_b[i], hd, p.v[i], nullptr, s));
+        TR_RC(tr_lin(p.x[i], Nn, 128, P->skip_w[i], P->skip_b[i], 64, p.sk[i], nullptr, s));
+        TR_RC(edgehip_attn_fwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.sk[i], p.conv[i], p.O[i], p.lse[i], stream));
+        TR_RC(edgehip_act_fwd(1, p.conv[i], Nn * 64, p.xs[i], stream));
+        TR_RC(tr_lin(p.xs[i], Nn, 64, P->gru_w_ih, P->gru_b_ih, 192, p.gi[i], nullptr, s));
+        TR_RC(tr_lin(p.hs[i], Nn, 64, P->gru_w_hh, P->gru_b_hh, 192, p.gh[i], nullptr, s));
+        TR_RC(edgehip_gru_gate_fwd(p.gi[i], p.gh[i], p.hs[i], Nn, p.hs[i + 1], stream));
+        TR_RC(edgehip_assemble_fwd(L, p.hs[i + 1], nullptr, p.cx[i], nullptr, 64, p.cin[i], stream));
+        TR_RC(tr_lin(p.cin[i], Nn, 128, P->context_w0, P->context_b0, 256, p.c1[i], p.c1s[i], s));
+        TR_RC(tr_lin(p.c1s[i], Nn, 256, P->context_w2, P->context_b2, 64, p.nctx[i], nullptr, s));
+        TR_RC(edgehip_segment_mean_fwd(L, p.nctx[i], p.cx[i], p.gin[i + 1], stream));
+        TR_RC(tr_global_fwd(P, p, i + 1, B, s));
+    }
+    // node_out_mlp on cat[nodes + contexts, X0] (layers.py:371-378), pair gather, final_out, CE
+    TR_RC(edgehip_assemble_fwd(L, p.hs[nl], p.cx[nl], nullptr, p.X0, 192, p.zin, stream));
+    TR_RC(tr_lin(p.zin, Nn, 256, P->node_out_w0, P->node_out_b0, 128, p.n1, p.n1s, s));
+    TR_RC(tr_lin(p.n1s, Nn, 128, P->node_out_w2, P->node_out_b2, 128, p.n2, p.n2s, s));
+    TR_RC(tr_lin(p.n2s, Nn, 128, P->node_out_w4, P->node_out_b4, 128, p.z, nullptr, s));
+    if (A == 0) return EDGEHIP_OK;
+    TR_RC(edgehip_pair_gather_add_fwd(p.z, 128, row, col, A, p.e, stream));
+    TR_RC(tr_lin(p.e, A, 128, P->final_w0, P->final_b0, 128, p.f1, p.f1s, s));
+    TR_RC(tr_lin(p.f1s, A, 128, P->final_w2, P->final_b2, 64, p.f2, p.f2s, s));
+    return edgehip_edge_ce_fwd(p.f2s, P->final_w4, P->final_b4, tgt, pair_graph, A, logits, ce_graph, stream);
+}
+
+extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                                      const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                      const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
+                                      const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream) {
+    EH_CHECK_ARG(L && P && G && adj_t && deg_t && d0 && flags && gce && ws && A >= 0);
+    EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph));
+    TR_RC(tr_check_net(P));
+    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A)) return EDGEHIP_ERR_WORKSPACE;
+    hipStream_t s = eh_stream(stream);
+    const int64_t Nn = L->num_nodes, B = L->num_graphs;
+    const int nl = P->num_layers;
+    if (Nn == 0 || B == 0 || A == 0) return EDGEHIP_OK;          // no active pair: the loss does not depend on the network
+    tr_plan p;
+    tr_make_plan(p, L, P, A, tr_ws_base(ws));
+#define GW(f) ((float*)G->f)
+    // weights transposed once per call (dX = dY W runs as a linear layer on W^T)
+    TR_RC(tr_transpose(P->node_in_w, 64, 192, p.wt_node_in, s));
+    TR_RC(tr_transpose(P->mlp_w2, 64, 256, p.wt_mlp2, s));
+    TR_RC(tr_transpose(P->global_w0, 256, 64, p.wt_g0, s));
+    TR_RC(tr_transpose(P->global_w2, 64, 256, p.wt_g2, s));
+    TR_RC(tr_transpose(P->context_w0, 256, 128, p.wt_c0, s));
+    TR_RC(tr_transpose(P->context_w2, 64, 256, p.wt_c2, s));
+    TR_RC(tr_transpose(P->gru_w_ih, 192, 64, p.wt_ih, s));
+    TR_RC(tr_transpose(P->gru_w_hh, 192, 64, p.wt_hh, s));
+    for (int i = 0; i < nl; ++i) {
+        const int hd = P->heads[i] * 64;
+        TR_RC(tr_transpose(P->time_w[i], 64, 64, p.wt_time[i], s));
+        TR_RC(tr_transpose(P->query_w[i], hd, 128, p.wt_q[i], s));
+        TR_RC(tr_transpose(P->key_w[i], hd, 128, p.wt_k[i], s));
+        TR_RC(tr_transpose(P->value_w[i], hd, 128, p.wt_v[i], s));
+        TR_RC(tr_transpose(P->skip_w[i], 64, 128, p.wt_sk[i], s));
+    }
+    TR_RC(tr_transpose(P->node_out_w0, 128, 256, p.wt_no0, s));
+    TR_RC(tr_transpose(P->node_out_w2, 128, 128, p.wt_no2, s));
+    TR_RC(tr_transpose(P->node_out_w4, 128, 128, p.wt_no4, s));
+    TR_RC(tr_transpose(P->final_w0, 128, 128, p.wt_f0, s));
+    TR_RC(tr_transpose(P->final_w2, 64, 128, p.wt_f2, s));
+
+    // CE + final_out (layers.py:381, active.py:157-175)
+    TR_RC(edgehip_edge_ce_bwd(p.f2s, P->final_w4, P->final_b4, tgt, pair_graph, gce, A, p.dA0, GW(final_w4), GW(final_b4), stream));
+    TR_RC(edgehip_act_bwd(1, p.f2, p.dA0, A * 64, p.dA0, stream));
+    TR_RC(edgehip_linear_bwd_weight(p.dA0, p.f1s, A, 64, 128, GW(final_w2), GW(final_b2), stream));
+    TR_RC(tr_lin_dx(p.dA0, A, 64, p.wt_f2, 128, p.dA1, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.f1, p.dA1, A * 128, p.dA1, stream));
+    TR_RC(edgehip_linear_bwd_weight(p.dA1, p.e, A, 128, 128, GW(final_w0), GW(final_b0), stream));
+    TR_RC(tr_lin_dx(p.dA1, A, 128, p.wt_f0, 128, p.dA0, 0, s));                       // dA0 = d e
+    float* dz = p.dx;                                                                  // [Nn,128]
+    TR_HIP(hipMemsetAsync(dz, 0, (size_t)Nn * 128 * sizeof(float), s));
+    TR_RC(edgehip_pair_gather_add_bwd(p.dA0, 128, row, col, A, dz, stream));
+    // node_out_mlp
+    float *dn = p.big1, *dn2 = p.big2, *dzin = p.big0;
+    TR_RC(edgehip_linear_bwd_weight(dz, p.n2s, Nn, 128, 128, GW(node_out_w4), GW(node_out_b4), stream));
+    TR_RC(tr_lin_dx(dz, Nn, 128, p.wt_no4, 128, dn, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.n2, dn, Nn * 128, dn, stream));
+    TR_RC(edgehip_linear_bwd_weight(dn, p.n1s, Nn, 128, 128, GW(node_out_w2), GW(node_out_b2), stream));
+    TR_RC(tr_lin_dx(dn, Nn, 128, p.wt_no2, 128, dn2, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.n1, dn2, Nn * 128, dn2, stream));
+    TR_RC(edgehip_linear_bwd_weight(dn2, p.zin, Nn, 128, 256, GW(node_out_w0), GW(node_out_b0), stream));
+    TR_RC(tr_lin_dx(dn2, Nn, 128, p.wt_no0, 256, dzin, 0, s));
+    // zin = [h + cx | X0]
+    float *dh = p.dh, *dh2 = p.dh2, *dcx = p.dcx, *ds = p.ds;
+    TR_RC(tr_slice(Nn, dzin, 256, 0, 64, dh, 0, s));
+    TR_RC(tr_segsum(L, dzin, 256, 0, dcx, 0, s));
+    TR_RC(tr_slice(Nn, dzin, 256, 64, 192, p.dX0, 0, s));
+    for (int i = nl - 1; i >= 0; --i) {
+        const int h = P->heads[i], hd = h * 64;
+        // cx[i+1] = global_mlp(mean(nctx_i) + cx[i])
+        TR_RC(tr_global_bwd(G, p, i + 1, B, dcx, ds, stream));                       // ds = d gin[i+1] = running d cx[i]
+        float* dnctx = p.dconv;
+        TR_RC(tr_segmean_bwd(L, ds, dnctx, 0, s));
+        TR_RC(edgehip_linear_bwd_weight(dnctx, p.c1s[i], Nn, 64, 256, GW(context_w2), GW(context_b2), stream));
+        float* dc1 = p.big2;
+        TR_RC(tr_lin_dx(dnctx, Nn, 64, p.wt_c2, 256, dc1, 0, s));
+        TR_RC(edgehip_act_bwd(1, p.c1[i], dc1, Nn * 256, dc1, stream));
+        TR_RC(edgehip_linear_bwd_weight(dc1, p.cin[i], Nn, 256, 128, GW(context_w0), GW(context_b0), stream));
+        TR_RC(tr_lin_dx(dc1, Nn, 256, p.wt_c0, 128, p.dx, 0, s));                    // d cin = [d h' | d cx[i] rows]
+        TR_RC(tr_slice(Nn, p.dx, 128, 0, 64, dh, 1, s));
+        TR_RC(tr_segsum(L, p.dx, 128, 64, ds, 1, s));
+        // GRU (layers.py:360)
+        float *dgi = p.big0, *dgh = p.big1;
+        TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], p.hs[i], dh, Nn, dgi, dgh, dh2, stream));
+        TR_RC(edgehip_linear_bwd_weight(dgi, p.xs[i], Nn, 192, 64, GW(gru_w_ih), GW(gru_b_ih), stream));
+        TR_RC(tr_lin_dx(dgi, Nn, 192, p.wt_ih, 64, p.dconv, 0, s));
+        TR_RC(edgehip_linear_bwd_weight(dgh, p.hs[i], Nn, 192, 64, GW(gru_w_hh), GW(gru_b_hh), stream));
+        TR_RC(tr_lin_dx(dgh, Nn, 192, p.wt_hh, 64, dh2, 1, s));
+        TR_RC(edgehip_act_bwd(1, p.conv[i], p.dconv, Nn * 64, p.dconv, stream));
+        // TransformerConv (layers.py:354)
+        float *dq = p.big0, *dk = p.big1, *dv = p.big2;
+        TR_RC(edgehip_attn_bwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.O[i], p.lse[i], p.dconv, p.Dbuf, dq, dk, dv, stream));
+        TR_RC(edgehip_linear_bwd_weight(dq, p.x[i], Nn, hd, 128, GW(query_w[i]), GW(query_b[i]), stream));
+        TR_RC(tr_lin_dx(dq, Nn, hd, p.wt_q[i], 128, p.dx, 0, s));
+        TR_RC(edgehip_linear_bwd_weight(dk, p.x[i], Nn, hd, 128, GW(key_w[i]), GW(key_b[i]), stream));
+        TR_RC(tr_lin_dx(dk, Nn, hd, p.wt_k[i], 128, p.dx, 1, s));
+        TR_RC(edgehip_linear_bwd_weight(dv, p.x[i], Nn, hd, 128, GW(value_w[i]), GW(value_b[i]), stream));
+        TR_RC(tr_lin_dx(dv, Nn, hd, p.wt_v[i], 128, p.dx, 1, s));
+        TR_RC(edgehip_linear_bwd_weight(p.dconv, p.x[i], Nn, 64, 128, GW(skip_w[i]), GW(skip_b[i]), stream));
+        TR_RC(tr_lin_dx(p.dconv, Nn, 64, p.wt_sk[i], 128, p.dx, 1, s));
+        // x = [h + cx (i > 0) | tl_g]
+        TR_RC(tr_slice(Nn, p.dx, 128, 0, 64, dh2, 1, s));
+        if (i > 0) TR_RC(tr_segsum(L, p.dx, 128, 0, ds, 1, s));
+        TR_RC(tr_segsum(L, p.dx, 128, 64, p.dtl, 0, s));
+        TR_RC(edgehip_linear_bwd_weight(p.dtl, p.mt, B, 64, 64, GW(time_w[i]), GW(time_b[i]), stream));
+        TR_RC(tr_lin_dx(p.dtl, B, 64, p.wt_time[i], 64, p.dmt, i != nl - 1, s));
+        float* t0 = dh; dh = dh2; dh2 = t0;
+        t0 = dcx; dcx = ds; ds = t0;
+    }
+    // first context, node_in, embeddings
+    TR_RC(tr_global_bwd(G, p, 0, B, dcx, ds, stream));
+    TR_RC(tr_segmean_bwd(L, ds, dh, 1, s));
+    TR_RC(edgehip_act_bwd(1, p.a0, dh, Nn * 64, dh, stream));
+    TR_RC(edgehip_linear_bwd_weight(dh, p.X0, Nn, 64, 192, GW(node_in_w), GW(node_in_b), stream));
+    TR_RC(tr_lin_dx(dh, Nn, 64, p.wt_node_in, 192, p.dX0, 1, s));
+    TR_RC(edgehip_train_embed_bwd(L, deg_t, d0, flags, P->max_degree, p.dX0, GW(embedding_t_w), GW(embedding_t_b),
+                                  GW(embedding_0_w), GW(embedding_0_b), GW(embedding_sel_w), stream));
+    // time mlp
+    TR_RC(edgehip_act_bwd(2, p.m2, p.dmt, B * 64, p.dmt, stream));
+    TR_RC(edgehip_linear_bwd_weight(p.dmt, p.m1s, B, 64, 256, GW(mlp_w2), GW(mlp_b2), stream));
+    TR_RC(tr_lin_dx(p.dmt, B, 64, p.wt_mlp2, 256, p.dm1, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.m1, p.dm1, B * 256, p.dm1, stream));
+    return edgehip_linear_bwd_weight(p.dm1, p.pe, B, 256, 64, GW(mlp_w0), GW(mlp_b0), stream);
+#undef GW
 }

@@ -98,10 +98,16 @@ EXPORTS = {
     'edgehip_pair_targets': [C.POINTER(Layout), vp, vp, vp, C.c_int64, vp, vp, vp],
     'edgehip_edge_ce_fwd': [vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp],
     'edgehip_edge_ce_bwd': [vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp],
+    # the whole differentiable network in two calls
+    'edgehip_train_forward': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp,
+                              vp, vp, C.c_size_t, vp],
+    'edgehip_train_backward': [C.POINTER(Layout), C.POINTER(GnnParams), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp,
+                               C.c_int64, vp, vp, vp, vp, C.c_size_t, vp],
 }
 SIZE_EXPORTS = {
     'edgehip_gnn_folded_floats': [C.POINTER(GnnParams)],
     'edgehip_gnn_workspace_bytes': [C.POINTER(Layout), C.POINTER(GnnParams)],
+    'edgehip_train_workspace_bytes': [C.POINTER(Layout), C.POINTER(GnnParams), C.c_int64],
 }
 
 

@@ -141,6 +141,60 @@ class TGNN_degree_guided(nn.Module):
         self._folded_key = None
 
     # ---- C structs ----------------------------------------------------------------------
+    def param_slots(self):
+        """[(field of edgehip_gnn_params, layer index or None, parameter)]: which tensor each pointer of the
+        C struct addresses (SURVEY App. C names)."""
+        out = [('embedding_t_w', None, self.embedding_t.weight), ('embedding_t_b', None, self.embedding_t.bias),
+               ('embedding_0_w', None, self.embedding_0.weight), ('embedding_0_b', None, self.embedding_0.bias),
+               ('embedding_sel_w', None, self.embedding_sel.weight),
+               ('node_in_w', None, self.node_in[0].weight), ('node_in_b', None, self.node_in[0].bias)]
+        for nm, m in (('mlp', self.mlp), ('global', self.global_mlp), ('context', self.context_mlp)):
+            out += [(f'{nm}_w0', None, m[0].weight), (f'{nm}_b0', None, m[0].bias),
+                    (f'{nm}_w2', None, m[2].weight), (f'{nm}_b2', None, m[2].bias)]
+        out += [('gru_w_ih', None, self.gru.weight_ih_l0), ('gru_w_hh', None, self.gru.weight_hh_l0),
+                ('gru_b_ih', None, self.gru.bias_ih_l0), ('gru_b_hh', None, self.gru.bias_hh_l0)]
+        for i in range(len(self.num_heads)):
+            tm, cv = self.layers[f'time{i}'], self.layers[f'conv{i}']
+            out += [('time_w', i, tm.linear.weight), ('time_b', i, tm.linear.bias),
+                    ('query_w', i, cv.lin_query.weight), ('query_b', i, cv.lin_query.bias),
+                    ('key_w', i, cv.lin_key.weight), ('key_b', i, cv.lin_key.bias),
+                    ('value_w', i, cv.lin_value.weight), ('value_b', i, cv.lin_value.bias),
+                    ('skip_w', i, cv.lin_skip.weight), ('skip_b', i, cv.lin_skip.bias)]
+        for j, k in ((0, '0'), (2, '2'), (4, '4')):
+            out += [(f'node_out_w{k}', None, self.node_out_mlp[j].weight), (f'node_out_b{k}', None, self.node_out_mlp[j].bias),
+                    (f'final_w{k}', None, self.final_out[j].weight), (f'final_b{k}', None, self.final_out[j].bias)]
+        return out
+
+    def fill_struct(self, P, address_of):
+        """Sets every parameter pointer of `P` to address_of(parameter) (the parameter itself, or its gradient)."""
+        for field, layer, prm in self.param_slots():
+            if layer is None:
+                setattr(P, field, address_of(prm))
+            else:
+                getattr(P, field)[layer] = address_of(prm)
+
+    def raw_params(self):
+        """GnnParams over the raw parameters only (no folding): what the training calls read."""
+        dev = self.embedding_t.weight.device
+        if dev.type != 'cuda':
+            raise capi.EdgeHipError('the model must live on a GPU (model.to("cuda")); there is no CPU path')
+        ps = list(self.parameters())
+        key = (dev, tuple(p.data_ptr() for p in ps))
+        if getattr(self, '_raw_key', None) == key:
+            return self._raw
+        for p in ps:
+            assert p.dtype == torch.float32 and p.is_contiguous()
+        if self._pos_emb is None or self._pos_emb.device != dev:
+            self._pos_emb = tables.pos_emb_table(self.num_steps, self.dim).to(dev)
+        P = capi.GnnParams()
+        P.dim, P.num_layers, P.max_degree, P.num_steps = self.dim, len(self.num_heads), int(self.max_degree), self.num_steps
+        for i, h in enumerate(self.num_heads):
+            P.heads[i] = h
+        self.fill_struct(P, lambda t: t.data_ptr())
+        P.pos_emb = self._pos_emb.data_ptr()
+        self._raw, self._raw_key = P, key
+        return P
+
     def c_params(self):
         """(GnnParams, folded buffer); refolds when any parameter changed (version counters)."""
         dev = self.embedding_t.weight.device
@@ -158,27 +212,8 @@ class TGNN_degree_guided(nn.Module):
         P.dim, P.num_layers, P.max_degree, P.num_steps = self.dim, len(self.num_heads), int(self.max_degree), self.num_steps
         for i, h in enumerate(self.num_heads):
             P.heads[i] = h
-        d = lambda t: t.data_ptr()
-        P.embedding_t_w, P.embedding_t_b = d(self.embedding_t.weight), d(self.embedding_t.bias)
-        P.embedding_0_w, P.embedding_0_b = d(self.embedding_0.weight), d(self.embedding_0.bias)
-        P.embedding_sel_w = d(self.embedding_sel.weight)
-        P.node_in_w, P.node_in_b = d(self.node_in[0].weight), d(self.node_in[0].bias)
-        for nm, m in (('mlp', self.mlp), ('global', self.global_mlp), ('context', self.context_mlp)):
-            setattr(P, f'{nm}_w0', d(m[0].weight)); setattr(P, f'{nm}_b0', d(m[0].bias))
-            setattr(P, f'{nm}_w2', d(m[2].weight)); setattr(P, f'{nm}_b2', d(m[2].bias))
-        P.gru_w_ih, P.gru_w_hh = d(self.gru.weight_ih_l0), d(self.gru.weight_hh_l0)
-        P.gru_b_ih, P.gru_b_hh = d(self.gru.bias_ih_l0), d(self.gru.bias_hh_l0)
-        for i in range(len(self.num_heads)):
-            tm, cv = self.layers[f'time{i}'], self.layers[f'conv{i}']
-            P.time_w[i], P.time_b[i] = d(tm.linear.weight), d(tm.linear.bias)
-            P.query_w[i], P.query_b[i] = d(cv.lin_query.weight), d(cv.lin_query.bias)
-            P.key_w[i], P.key_b[i] = d(cv.lin_key.weight), d(cv.lin_key.bias)
-            P.value_w[i], P.value_b[i] = d(cv.lin_value.weight), d(cv.lin_value.bias)
-            P.skip_w[i], P.skip_b[i] = d(cv.lin_skip.weight), d(cv.lin_skip.bias)
-        for j, k in ((0, '0'), (2, '2'), (4, '4')):
-            setattr(P, f'node_out_w{k}', d(self.node_out_mlp[j].weight)); setattr(P, f'node_out_b{k}', d(self.node_out_mlp[j].bias))
-            setattr(P, f'final_w{k}', d(self.final_out[j].weight)); setattr(P, f'final_b{k}', d(self.final_out[j].bias))
-        P.pos_emb = d(self._pos_emb)
+        self.fill_struct(P, lambda t: t.data_ptr())
+        P.pos_emb = self._pos_emb.data_ptr()
         nfl = capi.lib.edgehip_gnn_folded_floats(byref(P))
         if nfl == 0:
             raise capi.EdgeHipError('edgehip_gnn_folded_floats: unsupported configuration')
@@ -487,8 +522,8 @@ class BinomialDiffusionActive(nn.Module):
             self.materialize_actives(batch)
             row, col = batch.active_row, batch.active_col
             tgt, pair_graph = train.pair_targets(batch, adj_tm1, row, col)
-            ce, logits = train.tgnn_ce_forward(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, row, col, tgt,
-                                               pair_graph)
+            fwd = train.tgnn_ce_forward if getattr(self, 'train_form', 'fused') == 'ops' else train.tgnn_ce_fused
+            ce, logits = fwd(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, row, col, tgt, pair_graph)
             npairs = batch.edges_per_graph.to(dev).float()
             n_act = (st['aptr'][1:] - st['aptr'][:-1]).float()
             kl = ce + 6.9078e-29 * (npairs - n_act) + 6.9078e-29 * npairs          # active.py:176-181

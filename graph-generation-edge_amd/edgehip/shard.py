@@ -110,3 +110,12 @@ def allreduce_gradients(params, bucket=None):
             p.grad.copy_(bucket[o:o + k].view_as(p))
         o += k
     return bucket
+
+
+def allreduce_flat(flat):
+    """SUM of a flat gradient arena over the ranks, in place (train.GradArena: p.grad are views into it, so
+    there is no pack / unpack)."""
+    td = _dist()
+    if td is not None:
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+    return flat

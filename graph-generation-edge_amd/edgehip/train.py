@@ -315,3 +315,121 @@ def tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pai
     fo = net.final_out
     e2 = act(linear(act(linear(e, fo[0])), fo[2]))
     return _EdgeCE.apply(e2, fo[4].weight, fo[4].bias, tgt, pair_graph, batch.num_graphs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# The same network as ONE autograd node: edgehip_train_forward / edgehip_train_backward queue every op
+# above from the library (csrc/train.hip section J).  `tgnn_ce_forward` (one node per op) stays as the
+# checkable form; tests compare the two.
+# ------------------------------------------------------------------------------------------------------
+class GradArena:
+    """One flat fp32 buffer holding the gradient of every parameter; p.grad are views into it.  The backward
+    call ADDS into it directly (nothing is returned through autograd), the data-parallel exchange all-reduces
+    it in place, and zeroing it is one memset."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self._by_ptr = {p.data_ptr(): v for p, v in zip(self.params, self.views)}
+
+    def matches(self, params):
+        ps = [p for p in params if p.requires_grad]
+        return len(ps) == len(self.params) and all(a.data_ptr() == b.data_ptr() for a, b in zip(ps, self.params))
+
+    def zero_and_attach(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def grad_of(self, p):
+        return self._by_ptr[p.data_ptr()]
+
+
+_ACTIVE_ARENA = [None]
+
+
+class use_arena:
+    """with use_arena(arena): backward of the fused node accumulates straight into the arena."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        self.prev = _ACTIVE_ARENA[0]
+        _ACTIVE_ARENA[0] = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _ACTIVE_ARENA[0] = self.prev
+
+
+class _FusedNet(Function):
+    @staticmethod
+    def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, *params):
+        L = batch.layout
+        P = net.raw_params()
+        A, B = row.numel(), batch.num_graphs
+        dev = adj_t.device
+        nbytes = lib.edgehip_train_workspace_bytes(byref(L), byref(P), A)
+        if nbytes == 0:
+            raise capi.EdgeHipError('edgehip_train_workspace_bytes: unsupported configuration')
+        ws = getattr(batch, '_train_ws', None)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            batch._train_ws = ws
+        ce = torch.empty(B, dtype=torch.float32, device=dev)
+        logits = torch.empty((A, 2), dtype=torch.float32, device=dev)
+        d0 = batch.degree_i32
+        capi.check(lib.edgehip_train_forward(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
+                                             flags.data_ptr(), t_graph.data_ptr(), capi.ptr(row), capi.ptr(col), A,
+                                             capi.ptr(tgt), capi.ptr(pair_graph), ce.data_ptr(), logits.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _s()), 'train_forward')
+        ctx.args = (net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params)
+        ctx.mark_non_differentiable(logits)
+        return ce, logits
+
+    @staticmethod
+    def backward(ctx, gce, _glogits):
+        net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params = ctx.args
+        L = batch.layout
+        arena = _ACTIVE_ARENA[0]
+        direct = arena is not None and arena.matches(params)
+        if direct:
+            grads = None
+            address = lambda p: arena.grad_of(p).data_ptr()
+        else:
+            flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=adj_t.device)
+            grads, o, by_ptr = [], 0, {}
+            for p in params:
+                g = flat[o:o + p.numel()].view_as(p)
+                grads.append(g)
+                by_ptr[p.data_ptr()] = g
+                o += p.numel()
+            address = lambda p: by_ptr[p.data_ptr()].data_ptr()
+        G = capi.GnnParams()
+        net.fill_struct(G, address)
+        gce = gce.contiguous()
+        capi.check(lib.edgehip_train_backward(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
+                                              d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
+                                              capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _s()), 'train_backward')
+        head = (None,) * 10
+        if direct:
+            return head + (None,) * len(params)
+        used = {prm.data_ptr() for _, _, prm in net.param_slots()}
+        return head + tuple(g if p.data_ptr() in used else None for p, g in zip(params, grads))
+
+
+def tgnn_ce_fused(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph):
+    """Same contract as tgnn_ce_forward, one autograd node."""
+    params = [p for p in net.parameters() if p.requires_grad]
+    if len(params) != sum(1 for _ in net.parameters()):
+        # frozen parameters: the op-by-op form lets autograd skip them
+        return tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph)
+    return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, *params)

@@ -16,17 +16,31 @@ def make_optimizer(model, lr=1e-3, momentum=0.9, momentum_sqr=0.999):
 
 
 def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=None, **log_prob_kwargs):
-    """Returns the global bits/dim of the step (python float is NOT forced: a 0-d tensor, no host sync)."""
+    """Returns the global bits/dim of the step (python float is NOT forced: a 0-d tensor, no host sync).
+    With `state` (a dict kept by the caller across steps) the gradients live in one flat arena: the fused
+    backward adds into it, the data-parallel all-reduce runs on it in place and zeroing it is one memset."""
+    from . import train
     model.train()
-    optimizer.zero_grad(set_to_none=True)
-    neg_vb = model.log_prob(batch, **log_prob_kwargs)                   # [B], differentiable
-    P = shard.sum_over_ranks(batch.num_entries, batch.device)
-    loss = -neg_vb.sum() / (math.log(2) * P)                            # diffusion/loss.py:10-12
-    loss.backward()
     params = [p for p in model.parameters()]
-    bucket = shard.allreduce_gradients(params, None if state is None else state.get('bucket'))
-    if state is not None:
-        state['bucket'] = bucket
+    arena = None
+    if state is not None and getattr(model, 'train_form', 'fused') == 'fused':
+        arena = state.get('arena')
+        if arena is None or not arena.matches(params):
+            arena = state['arena'] = train.GradArena(params)
+        arena.zero_and_attach()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    with train.use_arena(arena):
+        neg_vb = model.log_prob(batch, **log_prob_kwargs)                   # [B], differentiable
+        P = shard.sum_over_ranks(batch.num_entries, batch.device)
+        loss = -neg_vb.sum() / (math.log(2) * P)                            # diffusion/loss.py:10-12
+        loss.backward()
+    if arena is not None:
+        shard.allreduce_flat(arena.flat)
+    else:
+        bucket = shard.allreduce_gradients(params, None if state is None else state.get('bucket'))
+        if state is not None:
+            state['bucket'] = bucket
     if clip_value:
         torch.nn.utils.clip_grad_value_(params, clip_value)
     if clip_norm:

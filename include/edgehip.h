@@ -319,6 +319,29 @@ int edgehip_edge_ce_fwd(const float* e2, const float* W4, const float* b4, const
 int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float* b4, const uint8_t* tgt, const int32_t* pair_graph,
                         const float* gkl, int64_t A, float* de2, float* dW4, float* db4, void* stream);
 
+/* ---- the whole differentiable network in two calls ------------------------------------------------
+ * replaces: TGNN_degree_guided.forward layers/layers.py:315-383 + _compute_MC_KL_joint
+ *           diffusion_binomial_active.py:157-175 under autograd, and loss.backward() through them
+ *           (diffusion/experiment.py:29-33).
+ * The library queues the ops above itself (same kernels, same order), so a training step costs two host
+ * calls instead of one autograd node per op.  `row`,`col` [A] int64: the active pairs (global node ids,
+ * edgehip_active_pairs_enumerate); tgt/pair_graph from edgehip_pair_targets.  forward writes
+ * ce_graph[B] = sum_k CE_k and logits[A,2] and leaves every activation the backward needs in `ws`
+ * (edgehip_train_workspace_bytes(L,P,A) bytes, caller-owned, must stay untouched until backward returns).
+ * backward: gce[B] = dLoss/d ce_graph; G has the layout of P, its pointers address GRADIENT buffers of the
+ * parameters' shapes; gradients are ADDED (float atomics / read-modify-write), so the caller zero-fills them
+ * once per step.  pos_emb and the integer fields of G are ignored. */
+size_t edgehip_train_workspace_bytes(const edgehip_layout* L, const edgehip_gnn_params* P, int64_t A);
+int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                          const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
+                          const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
+                          const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
+                          void* stream);
+int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                           const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                           const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
+                           const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- statistics of the sampled graphs (next row after the path) ------------------------
  * replaces: the degree / triangle / assortativity part of compute_graph_statistics,
  *           eval_utils/graph_statistics.py:9-123,202-230,249-285 (consumer datasets/evaluator.py:27-37)

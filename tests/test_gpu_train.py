@@ -208,9 +208,11 @@ def test_edge_ce_vs_torch():
 
 @pytest.mark.parametrize('name,case', [('loss_toy', 'toy'), ('loss_toy_mid', 'toy'), ('loss_ragged', 'ragged'),
                                        ('loss_polblogs1', 'polblogs1')])
-def test_loss_gradient_vs_oracle_autograd(name, case):
+@pytest.mark.parametrize('form', ['fused', 'ops'])
+def test_loss_gradient_vs_oracle_autograd(name, case, form):
     """elbo_bpd(model, batch).backward() against torch autograd through the oracle on the same t, pt and
-    uniforms (the golden fixture pins the forward values of this very configuration)."""
+    uniforms (the golden fixture pins the forward values of this very configuration).  form 'fused': the
+    network is one autograd node (edgehip_train_forward / _backward); 'ops': one node per op."""
     import edgehip
     g = H.golden(name + '.npz')
     builder, T, wseed, useed = cases.CASES[case]
@@ -232,6 +234,7 @@ def test_loss_gradient_vs_oracle_autograd(name, case):
     # product
     model = H.build_model(params, T, int(g['max_degree']))
     model.train()
+    model.train_form = form
     b = H.graph_batch(graphs, degree_dtype=np.int64)
     want = {}
     nv = model.log_prob(b, t, pt, us[1].cuda(), us[3].cuda(), want)
@@ -262,8 +265,10 @@ def test_loss_gradient_vs_oracle_autograd(name, case):
     np.testing.assert_allclose(nv2.cpu().numpy(), nv.detach().cpu().numpy(), rtol=1e-4, atol=1e-12)
 
 
-def test_train_step_matches_oracle_adam_and_learns():
-    """One optimisation step (experiment.py:29-37 of the reference): parameters after Adam equal the ones
+@pytest.mark.parametrize('arena', [True, False])
+def test_train_step_matches_oracle_adam_and_learns(arena):
+    """arena: gradients in one flat buffer the fused backward adds into (train.GradArena).
+    One optimisation step (experiment.py:29-37 of the reference): parameters after Adam equal the ones
     obtained from the oracle's autograd gradients; a few more steps on the same (t, uniforms) lower the loss."""
     import edgehip
     g = H.golden('loss_ragged.npz')
@@ -289,6 +294,8 @@ def test_train_step_matches_oracle_adam_and_learns():
     opt = edgehip.make_optimizer(model)
     b = H.graph_batch(graphs, degree_dtype=np.int64)
     kw = dict(t=t, pt=pt, u_tm1=us[1].cuda(), u_t=us[3].cuda())
+    if arena:
+        kw['state'] = {}
     losses = [float(edgehip.train_step(model, b, opt, clip_value=1.0, **kw))]
     # Adam's first step moves every weight by lr * g / (|g| + 1e-8): where |g| ~ 1e-8 the step amplifies the
     # rounding noise of g, so the bound is 5% of lr element-wise and 0.1% of lr on average

@@ -19,17 +19,20 @@ def main():
     tb = edgehip.GraphBatch([n] * TB, degree=[deg] * TB, edges=[edges] * TB, device='cuda', degree_dtype=np.int64)
     model.rng_seed = 1
     opt = edgehip.make_optimizer(model)
+    state = {}
+    if len(sys.argv) > 2:
+        model.train_form = sys.argv[2]
     for _ in range(3):
-        edgehip.train_step(model, tb, opt, clip_value=1.0)
+        edgehip.train_step(model, tb, opt, clip_value=1.0, state=state)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
-        edgehip.train_step(model, tb, opt, clip_value=1.0)
+        edgehip.train_step(model, tb, opt, clip_value=1.0, state=state)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / 10
     capi.lib.edgehip_prof_enable(1)
     for _ in range(5):
-        edgehip.train_step(model, tb, opt, clip_value=1.0)
+        edgehip.train_step(model, tb, opt, clip_value=1.0, state=state)
     torch.cuda.synchronize()
     prof = capi.prof_collect()
     capi.lib.edgehip_prof_enable(0)
