@@ -88,8 +88,9 @@ struct eh_gemm_desc {
     int64_t M;                          // rows when tile_row0 == null
     const int32_t* m_dev;               // optional device-side row count overriding M
     int prof_id;                        // kernel class for the optional event timer (prof.h)
-    // training extras, honoured by the LDS-staged kernel only (k_gemm): Y += result instead of Y = result
-    // (fan-in of gradients), and a second output Y2 = SiLU(Y) so the pre-activation stays for the backward
+    // training extras, honoured by the LDS-staged kernel only (k_gemm): accum 1: Y += result instead of Y = result
+    // (fan-in of gradients), 2: float atomics into Y (several products of one grouped launch meet in Y); and a
+    // second output Y2 = SiLU(Y) so the pre-activation stays for the backward
     int accum;
     float* Y2;
 };
@@ -160,3 +161,7 @@ __device__ static inline void eh_gemm_packed_body(const eh_gemm_desc& d, int ng_
 // grid of the packed kernel for a descriptor: blocks along the row tiles (gx), column-group splits, groups per block
 void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nacc);
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream);
+// up to EH_GROUP_MAX independent products (N % 64 == 0 each) in one launch
+#define EH_GROUP_MAX 8
+struct eh_gemm_group { eh_gemm_desc d[EH_GROUP_MAX]; int gx[EH_GROUP_MAX], split[EH_GROUP_MAX], per[EH_GROUP_MAX]; };
+int eh_launch_gemm_group(const eh_gemm_desc* ds, int n, hipStream_t stream);

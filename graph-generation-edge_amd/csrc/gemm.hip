@@ -5,10 +5,9 @@
 #include "prof.h"
 
 template <int NACC>
-__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) {
-    __shared__ __attribute__((aligned(16))) float wt[NACC * 32 * EH_WPITCH];
+__device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by, float* wt) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    int tile = blockIdx.x * 4 + wave;
+    int tile = bx * 4 + wave;
     int ntiles;
     int64_t M = 0;
     if (d.tile_row0) {
@@ -17,7 +16,7 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
         M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
         ntiles = (int)((M + 31) / 32);
     }
-    if (blockIdx.x * 4 >= ntiles) return;          // block-uniform: nothing to do
+    if (bx * 4 >= ntiles) return;          // block-uniform: nothing to do
     const bool live = tile < ntiles;               // idle waves still stage weights and hit barriers
     if (!live) tile = ntiles - 1;
     int row0, rows, g = 0;
@@ -31,7 +30,7 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
     const float* ap = d.A + arow * d.lda + hh * 32;
     const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
     const int ng_total = d.N / (32 * NACC);
-    const int ng0 = blockIdx.y * ng_per_block;
+    const int ng0 = by * ng_per_block;
     const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
     const bool single = d.K == 64;
     eh_frag a;
@@ -67,6 +66,7 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
                     float v = acc[j][i] + add0;
                     if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
                     if (d.act == 1) v = eh_silu(v);
+                    if (d.accum == 2) { atomicAdd(d.Y + grow * d.ldy + col, v); continue; }
                     if (d.accum) v += d.Y[grow * d.ldy + col];
                     d.Y[grow * d.ldy + col] = v;
                     if (d.Y2) d.Y2[grow * d.ldy + col] = eh_silu(v);
@@ -74,6 +74,23 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
             }
         }
     }
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) {
+    __shared__ __attribute__((aligned(16))) float wt[NACC * 32 * EH_WPITCH];
+    eh_gemm_lds_body<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
+}
+
+// Several independent linear layers in ONE launch: blockIdx.z selects the descriptor.  At the training shapes
+// (a few thousand rows, K <= 512) a launch is latency-bound, so the q/k/v/skip/gru products of one layer
+// cost about as much together as the largest of them alone.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_gemm_group(eh_gemm_group g) {
+    __shared__ __attribute__((aligned(16))) float wt[NACC * 32 * EH_WPITCH];
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= g.gx[z] || (int)blockIdx.y >= g.split[z]) return;
+    eh_gemm_lds_body<NACC>(g.d[z], g.per[z], blockIdx.x, blockIdx.y, wt);
 }
 
 template <int NACC>
@@ -111,6 +128,31 @@ int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
         EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per));
     else
         EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<1>, dim3(gx, split), dim3(256), 0, stream, d, per));
+    if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+    return EDGEHIP_OK;
+}
+
+int eh_launch_gemm_group(const eh_gemm_desc* ds, int n, hipStream_t stream) {
+    if (n <= 0) return EDGEHIP_OK;
+    if (n > EH_GROUP_MAX) return EDGEHIP_ERR_ARG;
+    eh_gemm_group g = {};
+    int mx = 0, my = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const eh_gemm_desc& d = ds[i];
+        if (!d.A || !d.W || !d.Y) return EDGEHIP_ERR_ARG;
+        if (d.K <= 0 || d.N <= 0 || (d.K & 63) || (d.N & 63) || d.w_packed) return EDGEHIP_ERR_UNSUPPORTED;
+        if (d.A2 ? ((d.K1 & 63) || d.K1 <= 0 || d.K1 >= d.K) : (d.K1 != d.K)) return EDGEHIP_ERR_ARG;
+        if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;
+        int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
+        if (tiles <= 0) continue;
+        int gx, split, per, nacc;
+        eh_gemm_grid(d, gx, split, per, nacc);
+        g.d[m] = d; g.gx[m] = gx; g.split[m] = split; g.per[m] = per;
+        mx = gx > mx ? gx : mx; my = split > my ? split : my;
+        ++m;
+    }
+    if (m == 0) return EDGEHIP_OK;
+    EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL(k_gemm_group<2>, dim3(mx, my, m), dim3(256), 0, stream, g));
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }

@@ -834,8 +834,14 @@ struct tr_plan {
     float *wt_node_in, *wt_mlp2, *wt_g0, *wt_g2, *wt_c0, *wt_c2, *wt_ih, *wt_hh, *wt_time[EDGEHIP_MAX_LAYERS];
     float *wt_q[EDGEHIP_MAX_LAYERS], *wt_k[EDGEHIP_MAX_LAYERS], *wt_v[EDGEHIP_MAX_LAYERS], *wt_sk[EDGEHIP_MAX_LAYERS];
     float *wt_no0, *wt_no2, *wt_no4, *wt_f0, *wt_f2;
-    float *dA0, *dA1, *big0, *big1, *big2, *dx, *dh, *dh2, *dconv, *dX0, *Dbuf;
-    float *dcx, *ds, *dg1, *dtl, *dmt, *dm1;
+    // gradient buffers.  Every buffer a weight-gradient product reads is written ONCE per backward call, so those
+    // products can run on the side stream while the main stream walks on (no write-after-read hazards)
+    float *dA0, *dA1, *dA2, *dz, *dn, *dn2, *dzin, *dh, *dh2, *dX0, *Dbuf;
+    float *dcxj[EDGEHIP_MAX_LAYERS + 1], *dg1[EDGEHIP_MAX_LAYERS + 1];
+    float *dnctx[EDGEHIP_MAX_LAYERS], *dc1[EDGEHIP_MAX_LAYERS], *dcin[EDGEHIP_MAX_LAYERS], *dgi[EDGEHIP_MAX_LAYERS];
+    float *dgh[EDGEHIP_MAX_LAYERS], *dconv[EDGEHIP_MAX_LAYERS], *dq[EDGEHIP_MAX_LAYERS], *dk[EDGEHIP_MAX_LAYERS];
+    float *dv[EDGEHIP_MAX_LAYERS], *dx[EDGEHIP_MAX_LAYERS], *dtl[EDGEHIP_MAX_LAYERS];
+    float *dmt, *dm1, *dgin0;
     size_t floats;
 };
 
@@ -870,13 +876,18 @@ static void tr_make_plan(tr_plan& p, const edgehip_layout* L, const edgehip_gnn_
     }
     p.wt_no0 = b.take(128 * 256); p.wt_no2 = b.take(128 * 128); p.wt_no4 = b.take(128 * 128); p.wt_f0 = b.take(128 * 128);
     p.wt_f2 = b.take(64 * 128);
-    const size_t bigw = (size_t)(hmax * 64 > 256 ? hmax * 64 : 256);
-    p.dA0 = b.take(A * 128); p.dA1 = b.take(A * 128);
-    p.big0 = b.take(Nn * bigw); p.big1 = b.take(Nn * bigw); p.big2 = b.take(Nn * bigw);
-    p.dx = b.take(Nn * 128); p.dh = b.take(Nn * 64); p.dh2 = b.take(Nn * 64); p.dconv = b.take(Nn * 64); p.dX0 = b.take(Nn * 192);
-    p.Dbuf = b.take(Nn * hmax);
-    p.dcx = b.take(B * 64); p.ds = b.take(B * 64); p.dg1 = b.take(B * 256); p.dtl = b.take(B * 64); p.dmt = b.take(B * 64);
-    p.dm1 = b.take(B * 256);
+    p.dA0 = b.take(A * 64); p.dA1 = b.take(A * 128); p.dA2 = b.take(A * 128);
+    p.dz = b.take(Nn * 128); p.dn = b.take(Nn * 128); p.dn2 = b.take(Nn * 128); p.dzin = b.take(Nn * 256);
+    p.dh = b.take(Nn * 64); p.dh2 = b.take(Nn * 64); p.dX0 = b.take(Nn * 192); p.Dbuf = b.take(Nn * hmax);
+    for (size_t i = 0; i <= nl; ++i) { p.dcxj[i] = b.take(B * 64); p.dg1[i] = b.take(B * 256); }
+    for (size_t i = 0; i < nl; ++i) {
+        const size_t hd = (size_t)P->heads[i] * 64;
+        p.dnctx[i] = b.take(Nn * 64); p.dc1[i] = b.take(Nn * 256); p.dcin[i] = b.take(Nn * 128);
+        p.dgi[i] = b.take(Nn * 192); p.dgh[i] = b.take(Nn * 192); p.dconv[i] = b.take(Nn * 64);
+        p.dq[i] = b.take(Nn * hd); p.dk[i] = b.take(Nn * hd); p.dv[i] = b.take(Nn * hd);
+        p.dx[i] = b.take(Nn * 128); p.dtl[i] = b.take(B * 64);
+    }
+    p.dmt = b.take(B * 64); p.dm1 = b.take(B * 256); p.dgin0 = b.take(B * 64);
     p.floats = b.off;
 }
 
@@ -908,20 +919,26 @@ __global__ void k_tr_pos_gather(int B, const int32_t* t_graph, const float* pos_
 }
 
 // Y = X W^T + b (pre-activation kept), optional Y2 = SiLU(Y)
-static int tr_lin(const float* X, int64_t M, int K, const float* W, const float* b, int N, float* Y, float* Y2, hipStream_t s) {
-    if (M == 0) return EDGEHIP_OK;
+static eh_gemm_desc tr_desc_lin(const float* X, int64_t M, int K, const float* W, const float* b, int N, float* Y, float* Y2) {
     eh_gemm_desc d = {};
     d.A = X; d.lda = K; d.K1 = K; d.W = W; d.K = K; d.N = N; d.bias = b; d.Y = Y; d.ldy = N; d.M = M; d.prof_id = EH_K_TRAIN;
     d.Y2 = Y2;
-    return eh_launch_gemm(d, s);
+    return d;
 }
-// dX[M,K] (+)= dY[M,N] W[N,K], WT = W^T as [K,N]
-static int tr_lin_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum, hipStream_t s) {
+static int tr_lin(const float* X, int64_t M, int K, const float* W, const float* b, int N, float* Y, float* Y2, hipStream_t s) {
     if (M == 0) return EDGEHIP_OK;
+    return eh_launch_gemm(tr_desc_lin(X, M, K, W, b, N, Y, Y2), s);
+}
+// dX[M,K] (+)= dY[M,N] W[N,K], WT = W^T as [K,N]; accum 0 store, 1 add, 2 atomic add
+static eh_gemm_desc tr_desc_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum) {
     eh_gemm_desc d = {};
     d.A = dY; d.lda = N; d.K1 = N; d.W = WT; d.K = N; d.N = K; d.Y = dX; d.ldy = K; d.M = M; d.prof_id = EH_K_TRAIN;
     d.accum = accum;
-    return eh_launch_gemm(d, s);
+    return d;
+}
+static int tr_lin_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum, hipStream_t s) {
+    if (M == 0) return EDGEHIP_OK;
+    return eh_launch_gemm(tr_desc_dx(dY, M, N, WT, K, dX, accum), s);
 }
 static int tr_transpose(const float* W, int N, int K, float* WT, hipStream_t s) {
     EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, W, N, K, WT));
@@ -956,14 +973,57 @@ static int tr_global_fwd(const edgehip_gnn_params* P, const tr_plan& p, int j, i
     TR_RC(tr_lin(p.gin[j], B, 64, P->global_w0, P->global_b0, 256, p.g1[j], p.g1s[j], s));
     return tr_lin(p.g1s[j], B, 256, P->global_w2, P->global_b2, 64, p.cx[j], nullptr, s);
 }
-// d cx[j] (in p.dcx) -> d gin[j] (into p.ds); weight gradients accumulate
-static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, int64_t B, float* dcx, float* ds, void* st) {
+// Side stream for the weight-gradient products.  Nothing on the main stream waits for dW/db until the step ends,
+// so they are queued on a second HIP stream behind an event of the launch that produced their dY and overlap
+// with the latency-bound chain of input-gradient products (one per device, created on first use).
+#include <mutex>
+struct tr_aux_t { hipStream_t side = nullptr; hipEvent_t ev[160]; int nev = 0; bool ok = false; };
+static tr_aux_t g_tr_aux[16];
+static std::mutex g_tr_aux_mu;
+static tr_aux_t* tr_aux() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tr_aux_mu);
+    tr_aux_t& a = g_tr_aux[dev];
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (a.nev = 0; a.nev < 160; ++a.nev)
+            if (hipEventCreateWithFlags(&a.ev[a.nev], hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+struct tr_dw_ctx {
+    hipStream_t main; tr_aux_t* aux; int used;
+    // dW[N,K] += dY^T X, db[N] += colsum(dY) on the side stream, ordered after everything queued on main so far
+    int dw(const float* dY, const float* X, int64_t M, int N, int K, const float* dW, const float* db) {
+        hipStream_t s = main;
+        if (aux && used < aux->nev - 1) {               // the last event is kept for join()
+            if (hipEventRecord(aux->ev[used], main) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+            if (hipStreamWaitEvent(aux->side, aux->ev[used], 0) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+            ++used;
+            s = aux->side;
+        }
+        return edgehip_linear_bwd_weight(dY, X, M, N, K, (float*)dW, (float*)db, (void*)s);
+    }
+    int join() {                       // main waits for every product queued on the side stream
+        if (!aux || used == 0) return EDGEHIP_OK;
+        hipEvent_t e = aux->ev[aux->nev - 1];
+        if (hipEventRecord(e, aux->side) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+        if (hipStreamWaitEvent(main, e, 0) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
+        return EDGEHIP_OK;
+    }
+};
+
+// d cx[j] (p.dcxj[j]) -> d gin[j] (into ds); weight gradients accumulate
+static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, int64_t B, float* ds, tr_dw_ctx& W, void* st) {
     hipStream_t s = eh_stream(st);
-    TR_RC(edgehip_linear_bwd_weight(dcx, p.g1s[j], B, 64, 256, (float*)G->global_w2, (float*)G->global_b2, st));
-    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.g1[j], p.dg1, B * 256, p.dg1, st));
-    TR_RC(edgehip_linear_bwd_weight(p.dg1, p.gin[j], B, 256, 64, (float*)G->global_w0, (float*)G->global_b0, st));
-    return tr_lin_dx(p.dg1, B, 256, p.wt_g0, 64, ds, 0, s);
+    const float* dcx = p.dcxj[j];
+    TR_RC(W.dw(dcx, p.g1s[j], B, 64, 256, G->global_w2, G->global_b2));
+    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1[j], 0, s));
+    TR_RC(edgehip_act_bwd(1, p.g1[j], p.dg1[j], B * 256, p.dg1[j], st));
+    TR_RC(W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0));
+    return tr_lin_dx(p.dg1[j], B, 256, p.wt_g0, 64, ds, 0, s);
 }
 
 extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
@@ -996,18 +1056,25 @@ extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_
     // first context (layers.py:342-343)
     TR_RC(edgehip_segment_mean_fwd(L, p.hs[0], nullptr, p.gin[0], stream));
     TR_RC(tr_global_fwd(P, p, 0, B, s));
+    {   // the per-layer time embeddings depend on mt only: one grouped launch (layers.py:349)
+        eh_gemm_desc ds[EDGEHIP_MAX_LAYERS];
+        for (int i = 0; i < nl; ++i) ds[i] = tr_desc_lin(p.mt, B, 64, P->time_w[i], P->time_b[i], 64, p.tl[i], nullptr);
+        TR_RC(eh_launch_gemm_group(ds, nl, s));
+    }
     for (int i = 0; i < nl; ++i) {
         const int h = P->heads[i], hd = h * 64;
-        TR_RC(tr_lin(p.mt, B, 64, P->time_w[i], P->time_b[i], 64, p.tl[i], nullptr, s));
         TR_RC(edgehip_assemble_fwd(L, p.hs[i], i > 0 ? p.cx[i] : nullptr, p.tl[i], nullptr, 64, p.x[i], stream));
-        TR_RC(tr_lin(p.x[i], Nn, 128, P->query_w[i], P->query_b[i], hd, p.q[i], nullptr, s));
-        TR_RC(tr_lin(p.x[i], Nn, 128, P->key_w[i], P->key_b[i], hd, p.k[i], nullptr, s));
-        TR_RC(tr_lin(p.x[i], Nn, 128, P->value_w[i], P->value_b[i], hd, p.v[i], nullptr, s));
-        TR_RC(tr_lin(p.x[i], Nn, 128, P->skip_w[i], P->skip_b[i], 64, p.sk[i], nullptr, s));
+        {   // q, k, v, skip read x; the hidden half of the GRU reads h: five independent products, one launch
+            eh_gemm_desc ds[5] = {tr_desc_lin(p.x[i], Nn, 128, P->query_w[i], P->query_b[i], hd, p.q[i], nullptr),
+                                  tr_desc_lin(p.x[i], Nn, 128, P->key_w[i], P->key_b[i], hd, p.k[i], nullptr),
+                                  tr_desc_lin(p.x[i], Nn, 128, P->value_w[i], P->value_b[i], hd, p.v[i], nullptr),
+                                  tr_desc_lin(p.x[i], Nn, 128, P->skip_w[i], P->skip_b[i], 64, p.sk[i], nullptr),
+                                  tr_desc_lin(p.hs[i], Nn, 64, P->gru_w_hh, P->gru_b_hh, 192, p.gh[i], nullptr)};
+            TR_RC(eh_launch_gemm_group(ds, 5, s));
+        }
         TR_RC(edgehip_attn_fwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.sk[i], p.conv[i], p.O[i], p.lse[i], stream));
         TR_RC(edgehip_act_fwd(1, p.conv[i], Nn * 64, p.xs[i], stream));
         TR_RC(tr_lin(p.xs[i], Nn, 64, P->gru_w_ih, P->gru_b_ih, 192, p.gi[i], nullptr, s));
-        TR_RC(tr_lin(p.hs[i], Nn, 64, P->gru_w_hh, P->gru_b_hh, 192, p.gh[i], nullptr, s));
         TR_RC(edgehip_gru_gate_fwd(p.gi[i], p.gh[i], p.hs[i], Nn, p.hs[i + 1], stream));
         TR_RC(edgehip_assemble_fwd(L, p.hs[i + 1], nullptr, p.cx[i], nullptr, 64, p.cin[i], stream));
         TR_RC(tr_lin(p.cin[i], Nn, 128, P->context_w0, P->context_b0, 256, p.c1[i], p.c1s[i], s));
@@ -1065,87 +1132,92 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
     TR_RC(tr_transpose(P->final_w0, 128, 128, p.wt_f0, s));
     TR_RC(tr_transpose(P->final_w2, 64, 128, p.wt_f2, s));
 
+    tr_dw_ctx W{s, tr_aux(), 0};
     // CE + final_out (layers.py:381, active.py:157-175)
     TR_RC(edgehip_edge_ce_bwd(p.f2s, P->final_w4, P->final_b4, tgt, pair_graph, gce, A, p.dA0, GW(final_w4), GW(final_b4), stream));
     TR_RC(edgehip_act_bwd(1, p.f2, p.dA0, A * 64, p.dA0, stream));
-    TR_RC(edgehip_linear_bwd_weight(p.dA0, p.f1s, A, 64, 128, GW(final_w2), GW(final_b2), stream));
+    TR_RC(W.dw(p.dA0, p.f1s, A, 64, 128, G->final_w2, G->final_b2));
     TR_RC(tr_lin_dx(p.dA0, A, 64, p.wt_f2, 128, p.dA1, 0, s));
     TR_RC(edgehip_act_bwd(1, p.f1, p.dA1, A * 128, p.dA1, stream));
-    TR_RC(edgehip_linear_bwd_weight(p.dA1, p.e, A, 128, 128, GW(final_w0), GW(final_b0), stream));
-    TR_RC(tr_lin_dx(p.dA1, A, 128, p.wt_f0, 128, p.dA0, 0, s));                       // dA0 = d e
-    float* dz = p.dx;                                                                  // [Nn,128]
-    TR_HIP(hipMemsetAsync(dz, 0, (size_t)Nn * 128 * sizeof(float), s));
-    TR_RC(edgehip_pair_gather_add_bwd(p.dA0, 128, row, col, A, dz, stream));
+    TR_RC(W.dw(p.dA1, p.e, A, 128, 128, G->final_w0, G->final_b0));
+    TR_RC(tr_lin_dx(p.dA1, A, 128, p.wt_f0, 128, p.dA2, 0, s));                       // d e
+    TR_HIP(hipMemsetAsync(p.dz, 0, (size_t)Nn * 128 * sizeof(float), s));
+    TR_RC(edgehip_pair_gather_add_bwd(p.dA2, 128, row, col, A, p.dz, stream));
     // node_out_mlp
-    float *dn = p.big1, *dn2 = p.big2, *dzin = p.big0;
-    TR_RC(edgehip_linear_bwd_weight(dz, p.n2s, Nn, 128, 128, GW(node_out_w4), GW(node_out_b4), stream));
-    TR_RC(tr_lin_dx(dz, Nn, 128, p.wt_no4, 128, dn, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.n2, dn, Nn * 128, dn, stream));
-    TR_RC(edgehip_linear_bwd_weight(dn, p.n1s, Nn, 128, 128, GW(node_out_w2), GW(node_out_b2), stream));
-    TR_RC(tr_lin_dx(dn, Nn, 128, p.wt_no2, 128, dn2, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.n1, dn2, Nn * 128, dn2, stream));
-    TR_RC(edgehip_linear_bwd_weight(dn2, p.zin, Nn, 128, 256, GW(node_out_w0), GW(node_out_b0), stream));
-    TR_RC(tr_lin_dx(dn2, Nn, 128, p.wt_no0, 256, dzin, 0, s));
+    TR_RC(W.dw(p.dz, p.n2s, Nn, 128, 128, G->node_out_w4, G->node_out_b4));
+    TR_RC(tr_lin_dx(p.dz, Nn, 128, p.wt_no4, 128, p.dn, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.n2, p.dn, Nn * 128, p.dn, stream));
+    TR_RC(W.dw(p.dn, p.n1s, Nn, 128, 128, G->node_out_w2, G->node_out_b2));
+    TR_RC(tr_lin_dx(p.dn, Nn, 128, p.wt_no2, 128, p.dn2, 0, s));
+    TR_RC(edgehip_act_bwd(1, p.n1, p.dn2, Nn * 128, p.dn2, stream));
+    TR_RC(W.dw(p.dn2, p.zin, Nn, 128, 256, G->node_out_w0, G->node_out_b0));
+    TR_RC(tr_lin_dx(p.dn2, Nn, 128, p.wt_no0, 256, p.dzin, 0, s));
     // zin = [h + cx | X0]
-    float *dh = p.dh, *dh2 = p.dh2, *dcx = p.dcx, *ds = p.ds;
-    TR_RC(tr_slice(Nn, dzin, 256, 0, 64, dh, 0, s));
-    TR_RC(tr_segsum(L, dzin, 256, 0, dcx, 0, s));
-    TR_RC(tr_slice(Nn, dzin, 256, 64, 192, p.dX0, 0, s));
+    float *dh = p.dh, *dh2 = p.dh2;
+    TR_RC(tr_slice(Nn, p.dzin, 256, 0, 64, dh, 0, s));
+    TR_RC(tr_segsum(L, p.dzin, 256, 0, p.dcxj[nl], 0, s));
+    TR_RC(tr_slice(Nn, p.dzin, 256, 64, 192, p.dX0, 0, s));
     for (int i = nl - 1; i >= 0; --i) {
         const int h = P->heads[i], hd = h * 64;
+        float* ds = p.dcxj[i];                                                         // running d cx[i]
         // cx[i+1] = global_mlp(mean(nctx_i) + cx[i])
-        TR_RC(tr_global_bwd(G, p, i + 1, B, dcx, ds, stream));                       // ds = d gin[i+1] = running d cx[i]
-        float* dnctx = p.dconv;
-        TR_RC(tr_segmean_bwd(L, ds, dnctx, 0, s));
-        TR_RC(edgehip_linear_bwd_weight(dnctx, p.c1s[i], Nn, 64, 256, GW(context_w2), GW(context_b2), stream));
-        float* dc1 = p.big2;
-        TR_RC(tr_lin_dx(dnctx, Nn, 64, p.wt_c2, 256, dc1, 0, s));
-        TR_RC(edgehip_act_bwd(1, p.c1[i], dc1, Nn * 256, dc1, stream));
-        TR_RC(edgehip_linear_bwd_weight(dc1, p.cin[i], Nn, 256, 128, GW(context_w0), GW(context_b0), stream));
-        TR_RC(tr_lin_dx(dc1, Nn, 256, p.wt_c0, 128, p.dx, 0, s));                    // d cin = [d h' | d cx[i] rows]
-        TR_RC(tr_slice(Nn, p.dx, 128, 0, 64, dh, 1, s));
-        TR_RC(tr_segsum(L, p.dx, 128, 64, ds, 1, s));
+        TR_RC(tr_global_bwd(G, p, i + 1, B, ds, W, stream));
+        TR_RC(tr_segmean_bwd(L, ds, p.dnctx[i], 0, s));
+        TR_RC(W.dw(p.dnctx[i], p.c1s[i], Nn, 64, 256, G->context_w2, G->context_b2));
+        TR_RC(tr_lin_dx(p.dnctx[i], Nn, 64, p.wt_c2, 256, p.dc1[i], 0, s));
+        TR_RC(edgehip_act_bwd(1, p.c1[i], p.dc1[i], Nn * 256, p.dc1[i], stream));
+        TR_RC(W.dw(p.dc1[i], p.cin[i], Nn, 256, 128, G->context_w0, G->context_b0));
+        TR_RC(tr_lin_dx(p.dc1[i], Nn, 256, p.wt_c0, 128, p.dcin[i], 0, s));          // d cin = [d h' | d cx[i] rows]
+        TR_RC(tr_slice(Nn, p.dcin[i], 128, 0, 64, dh, 1, s));
+        TR_RC(tr_segsum(L, p.dcin[i], 128, 64, ds, 1, s));
         // GRU (layers.py:360)
-        float *dgi = p.big0, *dgh = p.big1;
-        TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], p.hs[i], dh, Nn, dgi, dgh, dh2, stream));
-        TR_RC(edgehip_linear_bwd_weight(dgi, p.xs[i], Nn, 192, 64, GW(gru_w_ih), GW(gru_b_ih), stream));
-        TR_RC(tr_lin_dx(dgi, Nn, 192, p.wt_ih, 64, p.dconv, 0, s));
-        TR_RC(edgehip_linear_bwd_weight(dgh, p.hs[i], Nn, 192, 64, GW(gru_w_hh), GW(gru_b_hh), stream));
-        TR_RC(tr_lin_dx(dgh, Nn, 192, p.wt_hh, 64, dh2, 1, s));
-        TR_RC(edgehip_act_bwd(1, p.conv[i], p.dconv, Nn * 64, p.dconv, stream));
+        TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], p.hs[i], dh, Nn, p.dgi[i], p.dgh[i], dh2, stream));
+        TR_RC(W.dw(p.dgi[i], p.xs[i], Nn, 192, 64, G->gru_w_ih, G->gru_b_ih));
+        TR_RC(W.dw(p.dgh[i], p.hs[i], Nn, 192, 64, G->gru_w_hh, G->gru_b_hh));
+        {
+            eh_gemm_desc ds[2] = {tr_desc_dx(p.dgi[i], Nn, 192, p.wt_ih, 64, p.dconv[i], 0),
+                                  tr_desc_dx(p.dgh[i], Nn, 192, p.wt_hh, 64, dh2, 1)};
+            TR_RC(eh_launch_gemm_group(ds, 2, s));
+        }
+        TR_RC(edgehip_act_bwd(1, p.conv[i], p.dconv[i], Nn * 64, p.dconv[i], stream));
         // TransformerConv (layers.py:354)
-        float *dq = p.big0, *dk = p.big1, *dv = p.big2;
-        TR_RC(edgehip_attn_bwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.O[i], p.lse[i], p.dconv, p.Dbuf, dq, dk, dv, stream));
-        TR_RC(edgehip_linear_bwd_weight(dq, p.x[i], Nn, hd, 128, GW(query_w[i]), GW(query_b[i]), stream));
-        TR_RC(tr_lin_dx(dq, Nn, hd, p.wt_q[i], 128, p.dx, 0, s));
-        TR_RC(edgehip_linear_bwd_weight(dk, p.x[i], Nn, hd, 128, GW(key_w[i]), GW(key_b[i]), stream));
-        TR_RC(tr_lin_dx(dk, Nn, hd, p.wt_k[i], 128, p.dx, 1, s));
-        TR_RC(edgehip_linear_bwd_weight(dv, p.x[i], Nn, hd, 128, GW(value_w[i]), GW(value_b[i]), stream));
-        TR_RC(tr_lin_dx(dv, Nn, hd, p.wt_v[i], 128, p.dx, 1, s));
-        TR_RC(edgehip_linear_bwd_weight(p.dconv, p.x[i], Nn, 64, 128, GW(skip_w[i]), GW(skip_b[i]), stream));
-        TR_RC(tr_lin_dx(p.dconv, Nn, 64, p.wt_sk[i], 128, p.dx, 1, s));
+        TR_RC(edgehip_attn_bwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.O[i], p.lse[i], p.dconv[i], p.Dbuf, p.dq[i], p.dk[i],
+                               p.dv[i], stream));
+        TR_RC(W.dw(p.dq[i], p.x[i], Nn, hd, 128, G->query_w[i], G->query_b[i]));
+        TR_RC(W.dw(p.dk[i], p.x[i], Nn, hd, 128, G->key_w[i], G->key_b[i]));
+        TR_RC(W.dw(p.dv[i], p.x[i], Nn, hd, 128, G->value_w[i], G->value_b[i]));
+        TR_RC(W.dw(p.dconv[i], p.x[i], Nn, 64, 128, G->skip_w[i], G->skip_b[i]));
+        {   // the four input-gradient products meet in dx (float atomics onto a zero-filled buffer), one launch
+            TR_HIP(hipMemsetAsync(p.dx[i], 0, (size_t)Nn * 128 * sizeof(float), s));
+            eh_gemm_desc ds[4] = {tr_desc_dx(p.dq[i], Nn, hd, p.wt_q[i], 128, p.dx[i], 2),
+                                  tr_desc_dx(p.dk[i], Nn, hd, p.wt_k[i], 128, p.dx[i], 2),
+                                  tr_desc_dx(p.dv[i], Nn, hd, p.wt_v[i], 128, p.dx[i], 2),
+                                  tr_desc_dx(p.dconv[i], Nn, 64, p.wt_sk[i], 128, p.dx[i], 2)};
+            TR_RC(eh_launch_gemm_group(ds, 4, s));
+        }
         // x = [h + cx (i > 0) | tl_g]
-        TR_RC(tr_slice(Nn, p.dx, 128, 0, 64, dh2, 1, s));
-        if (i > 0) TR_RC(tr_segsum(L, p.dx, 128, 0, ds, 1, s));
-        TR_RC(tr_segsum(L, p.dx, 128, 64, p.dtl, 0, s));
-        TR_RC(edgehip_linear_bwd_weight(p.dtl, p.mt, B, 64, 64, GW(time_w[i]), GW(time_b[i]), stream));
-        TR_RC(tr_lin_dx(p.dtl, B, 64, p.wt_time[i], 64, p.dmt, i != nl - 1, s));
+        TR_RC(tr_slice(Nn, p.dx[i], 128, 0, 64, dh2, 1, s));
+        if (i > 0) TR_RC(tr_segsum(L, p.dx[i], 128, 0, ds, 1, s));
+        TR_RC(tr_segsum(L, p.dx[i], 128, 64, p.dtl[i], 0, s));
+        TR_RC(W.dw(p.dtl[i], p.mt, B, 64, 64, G->time_w[i], G->time_b[i]));
+        TR_RC(tr_lin_dx(p.dtl[i], B, 64, p.wt_time[i], 64, p.dmt, i != nl - 1, s));
         float* t0 = dh; dh = dh2; dh2 = t0;
-        t0 = dcx; dcx = ds; ds = t0;
     }
     // first context, node_in, embeddings
-    TR_RC(tr_global_bwd(G, p, 0, B, dcx, ds, stream));
-    TR_RC(tr_segmean_bwd(L, ds, dh, 1, s));
+    float* dgin0 = p.dgin0;
+    TR_RC(tr_global_bwd(G, p, 0, B, dgin0, W, stream));
+    TR_RC(tr_segmean_bwd(L, dgin0, dh, 1, s));
     TR_RC(edgehip_act_bwd(1, p.a0, dh, Nn * 64, dh, stream));
-    TR_RC(edgehip_linear_bwd_weight(dh, p.X0, Nn, 64, 192, GW(node_in_w), GW(node_in_b), stream));
+    TR_RC(W.dw(dh, p.X0, Nn, 64, 192, G->node_in_w, G->node_in_b));
     TR_RC(tr_lin_dx(dh, Nn, 64, p.wt_node_in, 192, p.dX0, 1, s));
     TR_RC(edgehip_train_embed_bwd(L, deg_t, d0, flags, P->max_degree, p.dX0, GW(embedding_t_w), GW(embedding_t_b),
                                   GW(embedding_0_w), GW(embedding_0_b), GW(embedding_sel_w), stream));
     // time mlp
     TR_RC(edgehip_act_bwd(2, p.m2, p.dmt, B * 64, p.dmt, stream));
-    TR_RC(edgehip_linear_bwd_weight(p.dmt, p.m1s, B, 64, 256, GW(mlp_w2), GW(mlp_b2), stream));
+    TR_RC(W.dw(p.dmt, p.m1s, B, 64, 256, G->mlp_w2, G->mlp_b2));
     TR_RC(tr_lin_dx(p.dmt, B, 64, p.wt_mlp2, 256, p.dm1, 0, s));
     TR_RC(edgehip_act_bwd(1, p.m1, p.dm1, B * 256, p.dm1, stream));
-    return edgehip_linear_bwd_weight(p.dm1, p.pe, B, 256, 64, GW(mlp_w0), GW(mlp_b0), stream);
+    TR_RC(W.dw(p.dm1, p.pe, B, 256, 64, G->mlp_w0, G->mlp_b0));
+    return W.join();
 #undef GW
 }

@@ -460,21 +460,29 @@ class BinomialDiffusionActive(nn.Module):
     def _kl_prior(self, batch):
         """diffusion_binomial_vanilla.py:116-136.  Every element of a class contributes the same
         value, so the per-graph sum is count x value (three values, computed with the reference's ops)."""
-        T = self.num_timesteps
-        b = self._host_buf
-        la, l1a = b['log_cumprod_alpha'][T - 1], b['log_1_min_cumprod_alpha'][T - 1]
-        zero = torch.log(torch.tensor([[1.0, 1e-30]]))
-        one = torch.log(torch.tensor([[1e-30, 1.0]]))
+        cached = getattr(batch, '_kl_prior_cache', None)
+        if cached is not None and cached[0] is self:
+            return cached[1]
+        consts = getattr(self, '_kl_consts', None)
+        if consts is None:
+            T = self.num_timesteps
+            b = self._host_buf
+            la, l1a = b['log_cumprod_alpha'][T - 1], b['log_1_min_cumprod_alpha'][T - 1]
+            zero = torch.log(torch.tensor([[1.0, 1e-30]]))
+            one = torch.log(torch.tensor([[1e-30, 1.0]]))
 
-        def kl(x, lf):
-            q = tables._log_add_exp(x + la, l1a + lf)
-            return float((q.exp() * (q - lf)).sum(dim=1).double())
-        kn = kl(zero, b['log_final_prob_node'])
-        k0, k1 = kl(zero, b['log_final_prob_edge']), kl(one, b['log_final_prob_edge'])
+            def kl(x, lf):
+                q = tables._log_add_exp(x + la, l1a + lf)
+                return float((q.exp() * (q - lf)).sum(dim=1).double())
+            consts = self._kl_consts = (kl(zero, b['log_final_prob_node']), kl(zero, b['log_final_prob_edge']),
+                                        kl(one, b['log_final_prob_edge']))
+        kn, k0, k1 = consts
         n = batch.nodes_per_graph.double()
         P = batch.edges_per_graph.double()
         E = _x0_edge_counts(batch).double()
-        return (n * kn + (P - E) * k0 + E * k1).float()
+        out = (n * kn + (P - E) * k0 + E * k1).float()
+        batch._kl_prior_cache = (self, out)        # x0, the sizes and the schedule are fixed for a batch object
+        return out
 
     # ---- a18, a21 : loss -------------------------------------------------------------------------
     def log_prob(self, batch, t=None, pt=None, u_tm1=None, u_t=None, want=None):

@@ -11,8 +11,15 @@ from . import shard
 
 
 def make_optimizer(model, lr=1e-3, momentum=0.9, momentum_sqr=0.999):
-    """The reference default: Adam(lr 1e-3, betas (0.9, 0.999)) (diffusion/optim/multistep.py:27-46)."""
-    return torch.optim.Adam(model.parameters(), lr=lr, betas=(momentum, momentum_sqr))
+    """The reference default: Adam(lr 1e-3, betas (0.9, 0.999)) (diffusion/optim/multistep.py:27-46).  On the GPU
+    torch's fused implementation is used (same update rule, one multi-tensor launch instead of ~13)."""
+    params = list(model.parameters())
+    if params and params[0].is_cuda:
+        try:
+            return torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr), fused=True)
+        except (RuntimeError, TypeError):
+            pass
+    return torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr))
 
 
 def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=None, **log_prob_kwargs):
@@ -41,7 +48,9 @@ def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=N
         bucket = shard.allreduce_gradients(params, None if state is None else state.get('bucket'))
         if state is not None:
             state['bucket'] = bucket
-    if clip_value:
+    if clip_value and arena is not None:
+        arena.flat.clamp_(-clip_value, clip_value)          # every p.grad is a view of the arena: one launch
+    elif clip_value:
         torch.nn.utils.clip_grad_value_(params, clip_value)
     if clip_norm:
         torch.nn.utils.clip_grad_norm_(params, clip_norm)
