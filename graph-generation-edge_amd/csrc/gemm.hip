@@ -7,7 +7,8 @@
 template <int NACC>
 __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by, float* wt) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    int tile = bx * 4 + wave;
+    const int nw = blockDim.x >> 6;                // waves per block: 4, or 1 for small problems (more, shorter blocks)
+    int tile = bx * nw + wave;
     int ntiles;
     int64_t M = 0;
     if (d.tile_row0) {
@@ -16,7 +17,7 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
         M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
         ntiles = (int)((M + 31) / 32);
     }
-    if (bx * 4 >= ntiles) return;          // block-uniform: nothing to do
+    if (bx * nw >= ntiles) return;         // block-uniform: nothing to do
     const bool live = tile < ntiles;               // idle waves still stage weights and hit barriers
     if (!live) tile = ntiles - 1;
     int row0, rows, g = 0;
@@ -66,6 +67,11 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
                     float v = acc[j][i] + add0;
                     if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
                     if (d.act == 1) v = eh_silu(v);
+                    if (d.dact) {
+                        const float x = d.dact[grow * d.ldy + col];
+                        const float sg = 1.0f / (1.0f + expf(-x));
+                        v *= sg * (1.0f + x * (1.0f - sg));
+                    }
                     if (d.accum == 2) { atomicAdd(d.Y + grow * d.ldy + col, v); continue; }
                     if (d.accum) v += d.Y[grow * d.ldy + col];
                     d.Y[grow * d.ldy + col] = v;
@@ -109,25 +115,52 @@ void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nac
     split = (ng_total + per - 1) / per;
 }
 
+// Launch shape of the LDS-staged kernel: 4 waves per block sharing a weight tile, 64 columns per wave.
+// Cutting small problems finer (one wave per block, 32 columns per wave: 4x-8x more, shorter blocks) was measured
+// on the training step and is SLOWER (polblogs B=4: 6.44 vs 5.08 ms per step; B=32: 13.75 vs 12.59): every wave
+// then stages its own weight tile.  The switch stays for experiments (target > 0 enables it).
+struct eh_gemm_cfg { int nacc, nw, gx, split, per; };
+static eh_gemm_cfg eh_gemm_config(const eh_gemm_desc& d, int force_nacc2) {
+    const int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
+    eh_gemm_cfg c;
+    c.nacc = (d.N % 64 == 0) ? 2 : 1;
+    c.nw = 4;
+    const int64_t target = 0;
+    if (((tiles + 3) / 4) * (d.N / (32 * c.nacc)) < target) {
+        c.nw = 1;
+        if (!force_nacc2 && tiles * (d.N / (32 * c.nacc)) < target) c.nacc = 1;
+    }
+    c.gx = (int)((tiles + c.nw - 1) / c.nw);
+    const int ng_total = d.N / (32 * c.nacc);
+    int want = (2048 + c.gx - 1) / c.gx;
+    c.split = want < 1 ? 1 : (want > ng_total ? ng_total : want);
+    c.per = (ng_total + c.split - 1) / c.split;
+    c.split = (ng_total + c.per - 1) / c.per;
+    return c;
+}
+
 int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
     if (!d.A || !d.W || !d.Y) return EDGEHIP_ERR_ARG;
-    if (d.w_packed && (d.accum || d.Y2)) return EDGEHIP_ERR_UNSUPPORTED;
+    if (d.w_packed && (d.accum || d.Y2 || d.dact)) return EDGEHIP_ERR_UNSUPPORTED;
     if (d.K <= 0 || d.N <= 0 || (d.K & 63) || (d.N & 31)) return EDGEHIP_ERR_UNSUPPORTED;
     if (d.A2 ? ((d.K1 & 63) || d.K1 <= 0 || d.K1 >= d.K) : (d.K1 != d.K)) return EDGEHIP_ERR_ARG;
     if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;
     int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
     if (tiles <= 0) return EDGEHIP_OK;
-    int gx, split, per, nacc;
-    eh_gemm_grid(d, gx, split, per, nacc);
     if (d.w_packed) {
+        int gx, split, per, nacc;
+        eh_gemm_grid(d, gx, split, per, nacc);
         if (nacc == 2)
             EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm_packed<2>, dim3(gx, split), dim3(256), 0, stream, d, per));
         else
             EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm_packed<1>, dim3(gx, split), dim3(256), 0, stream, d, per));
-    } else if (nacc == 2)
-        EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(gx, split), dim3(256), 0, stream, d, per));
-    else
-        EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<1>, dim3(gx, split), dim3(256), 0, stream, d, per));
+    } else {
+        const eh_gemm_cfg c = eh_gemm_config(d, 0);
+        if (c.nacc == 2)
+            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(c.gx, c.split), dim3(64 * c.nw), 0, stream, d, c.per));
+        else
+            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<1>, dim3(c.gx, c.split), dim3(64 * c.nw), 0, stream, d, c.per));
+    }
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }
@@ -137,6 +170,13 @@ int eh_launch_gemm_group(const eh_gemm_desc* ds, int n, hipStream_t stream) {
     if (n > EH_GROUP_MAX) return EDGEHIP_ERR_ARG;
     eh_gemm_group g = {};
     int mx = 0, my = 0, m = 0;
+    // one block shape for the whole group: 4 waves per block only if that still fills the chip
+    int64_t blocks4 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t tiles = ds[i].tile_row0 ? ds[i].num_tiles : (ds[i].M + 31) / 32;
+        blocks4 += ((tiles + 3) / 4) * (ds[i].N / 64);
+    }
+    const int nw = blocks4 < 0 ? 1 : 4;            // see eh_gemm_config: single-wave blocks measured slower
     for (int i = 0; i < n; ++i) {
         const eh_gemm_desc& d = ds[i];
         if (!d.A || !d.W || !d.Y) return EDGEHIP_ERR_ARG;
@@ -145,14 +185,17 @@ int eh_launch_gemm_group(const eh_gemm_desc* ds, int n, hipStream_t stream) {
         if ((d.lda & 3) || (d.A2 && (d.lda2 & 3))) return EDGEHIP_ERR_ARG;
         int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
         if (tiles <= 0) continue;
-        int gx, split, per, nacc;
-        eh_gemm_grid(d, gx, split, per, nacc);
+        const int gx = (int)((tiles + nw - 1) / nw), ng_total = d.N / 64;
+        int want = (2048 + gx - 1) / gx;
+        int split = want < 1 ? 1 : (want > ng_total ? ng_total : want);
+        const int per = (ng_total + split - 1) / split;
+        split = (ng_total + per - 1) / per;
         g.d[m] = d; g.gx[m] = gx; g.split[m] = split; g.per[m] = per;
         mx = gx > mx ? gx : mx; my = split > my ? split : my;
         ++m;
     }
     if (m == 0) return EDGEHIP_OK;
-    EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL(k_gemm_group<2>, dim3(mx, my, m), dim3(256), 0, stream, g));
+    EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL(k_gemm_group<2>, dim3(mx, my, m), dim3(64 * nw), 0, stream, g));
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }

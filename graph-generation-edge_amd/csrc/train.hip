@@ -930,15 +930,35 @@ static int tr_lin(const float* X, int64_t M, int K, const float* W, const float*
     return eh_launch_gemm(tr_desc_lin(X, M, K, W, b, N, Y, Y2), s);
 }
 // dX[M,K] (+)= dY[M,N] W[N,K], WT = W^T as [K,N]; accum 0 store, 1 add, 2 atomic add
-static eh_gemm_desc tr_desc_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum) {
+static eh_gemm_desc tr_desc_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum,
+                               const float* silu_pre = nullptr) {
     eh_gemm_desc d = {};
+    d.dact = silu_pre;
     d.A = dY; d.lda = N; d.K1 = N; d.W = WT; d.K = N; d.N = K; d.Y = dX; d.ldy = K; d.M = M; d.prof_id = EH_K_TRAIN;
     d.accum = accum;
     return d;
 }
-static int tr_lin_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum, hipStream_t s) {
+// silu_pre: dX is the gradient of SiLU(pre) -> multiply by SiLU'(pre) in the epilogue (accum must be 0)
+static int tr_lin_dx(const float* dY, int64_t M, int N, const float* WT, int K, float* dX, int accum, hipStream_t s,
+                     const float* silu_pre = nullptr) {
     if (M == 0) return EDGEHIP_OK;
-    return eh_launch_gemm(tr_desc_dx(dY, M, N, WT, K, dX, accum), s);
+    return eh_launch_gemm(tr_desc_dx(dY, M, N, WT, K, dX, accum, silu_pre), s);
+}
+// every weight of the network in one launch: blockIdx.z selects the matrix
+struct tr_tentry { const float* W; float* WT; int N, K; };
+#define TR_TMAX (13 + 5 * EDGEHIP_MAX_LAYERS)
+struct tr_tlist { tr_tentry e[TR_TMAX]; int n; };
+__global__ void k_tr_transpose_many(tr_tlist tl) {
+    __shared__ float t[32][33];
+    const tr_tentry e = tl.e[blockIdx.z];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    if (n0 >= e.N || k0 >= e.K) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < e.N && k0 + tx < e.K) t[r][tx] = e.W[(int64_t)(n0 + r) * e.K + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < e.K && n0 + tx < e.N) e.WT[(int64_t)(k0 + r) * e.N + n0 + tx] = t[tx][r];
 }
 static int tr_transpose(const float* W, int N, int K, float* WT, hipStream_t s) {
     EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, s, W, N, K, WT));
@@ -1020,9 +1040,8 @@ static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, i
     hipStream_t s = eh_stream(st);
     const float* dcx = p.dcxj[j];
     TR_RC(W.dw(dcx, p.g1s[j], B, 64, 256, G->global_w2, G->global_b2));
-    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1[j], 0, s));
-    TR_RC(edgehip_act_bwd(1, p.g1[j], p.dg1[j], B * 256, p.dg1[j], st));
-    TR_RC(W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0));
+    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1[j], 0, s, p.g1[j]));
+        TR_RC(W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0));
     return tr_lin_dx(p.dg1[j], B, 256, p.wt_g0, 64, ds, 0, s);
 }
 
@@ -1109,48 +1128,41 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
     tr_plan p;
     tr_make_plan(p, L, P, A, tr_ws_base(ws));
 #define GW(f) ((float*)G->f)
-    // weights transposed once per call (dX = dY W runs as a linear layer on W^T)
-    TR_RC(tr_transpose(P->node_in_w, 64, 192, p.wt_node_in, s));
-    TR_RC(tr_transpose(P->mlp_w2, 64, 256, p.wt_mlp2, s));
-    TR_RC(tr_transpose(P->global_w0, 256, 64, p.wt_g0, s));
-    TR_RC(tr_transpose(P->global_w2, 64, 256, p.wt_g2, s));
-    TR_RC(tr_transpose(P->context_w0, 256, 128, p.wt_c0, s));
-    TR_RC(tr_transpose(P->context_w2, 64, 256, p.wt_c2, s));
-    TR_RC(tr_transpose(P->gru_w_ih, 192, 64, p.wt_ih, s));
-    TR_RC(tr_transpose(P->gru_w_hh, 192, 64, p.wt_hh, s));
-    for (int i = 0; i < nl; ++i) {
-        const int hd = P->heads[i] * 64;
-        TR_RC(tr_transpose(P->time_w[i], 64, 64, p.wt_time[i], s));
-        TR_RC(tr_transpose(P->query_w[i], hd, 128, p.wt_q[i], s));
-        TR_RC(tr_transpose(P->key_w[i], hd, 128, p.wt_k[i], s));
-        TR_RC(tr_transpose(P->value_w[i], hd, 128, p.wt_v[i], s));
-        TR_RC(tr_transpose(P->skip_w[i], 64, 128, p.wt_sk[i], s));
+    {   // weights transposed once per call, all in one launch (dX = dY W runs as a linear layer on W^T)
+        tr_tlist tl = {};
+        auto add = [&tl](const float* W, int N, int K, float* WT) { tl.e[tl.n++] = tr_tentry{W, WT, N, K}; };
+        add(P->node_in_w, 64, 192, p.wt_node_in); add(P->mlp_w2, 64, 256, p.wt_mlp2);
+        add(P->global_w0, 256, 64, p.wt_g0); add(P->global_w2, 64, 256, p.wt_g2);
+        add(P->context_w0, 256, 128, p.wt_c0); add(P->context_w2, 64, 256, p.wt_c2);
+        add(P->gru_w_ih, 192, 64, p.wt_ih); add(P->gru_w_hh, 192, 64, p.wt_hh);
+        for (int i = 0; i < nl; ++i) {
+            const int hd = P->heads[i] * 64;
+            add(P->time_w[i], 64, 64, p.wt_time[i]); add(P->query_w[i], hd, 128, p.wt_q[i]); add(P->key_w[i], hd, 128, p.wt_k[i]);
+            add(P->value_w[i], hd, 128, p.wt_v[i]); add(P->skip_w[i], 64, 128, p.wt_sk[i]);
+        }
+        add(P->node_out_w0, 128, 256, p.wt_no0); add(P->node_out_w2, 128, 128, p.wt_no2); add(P->node_out_w4, 128, 128, p.wt_no4);
+        add(P->final_w0, 128, 128, p.wt_f0); add(P->final_w2, 64, 128, p.wt_f2);
+        int mk = 0, mn = 0;
+        for (int i = 0; i < tl.n; ++i) { mk = tl.e[i].K > mk ? tl.e[i].K : mk; mn = tl.e[i].N > mn ? tl.e[i].N : mn; }
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_transpose_many, dim3((mk + 31) / 32, (mn + 31) / 32, tl.n), dim3(256), 0, s, tl));
+        EH_LAUNCH_CHECK();
     }
-    TR_RC(tr_transpose(P->node_out_w0, 128, 256, p.wt_no0, s));
-    TR_RC(tr_transpose(P->node_out_w2, 128, 128, p.wt_no2, s));
-    TR_RC(tr_transpose(P->node_out_w4, 128, 128, p.wt_no4, s));
-    TR_RC(tr_transpose(P->final_w0, 128, 128, p.wt_f0, s));
-    TR_RC(tr_transpose(P->final_w2, 64, 128, p.wt_f2, s));
-
     tr_dw_ctx W{s, tr_aux(), 0};
     // CE + final_out (layers.py:381, active.py:157-175)
     TR_RC(edgehip_edge_ce_bwd(p.f2s, P->final_w4, P->final_b4, tgt, pair_graph, gce, A, p.dA0, GW(final_w4), GW(final_b4), stream));
     TR_RC(edgehip_act_bwd(1, p.f2, p.dA0, A * 64, p.dA0, stream));
     TR_RC(W.dw(p.dA0, p.f1s, A, 64, 128, G->final_w2, G->final_b2));
-    TR_RC(tr_lin_dx(p.dA0, A, 64, p.wt_f2, 128, p.dA1, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.f1, p.dA1, A * 128, p.dA1, stream));
-    TR_RC(W.dw(p.dA1, p.e, A, 128, 128, G->final_w0, G->final_b0));
+    TR_RC(tr_lin_dx(p.dA0, A, 64, p.wt_f2, 128, p.dA1, 0, s, p.f1));
+        TR_RC(W.dw(p.dA1, p.e, A, 128, 128, G->final_w0, G->final_b0));
     TR_RC(tr_lin_dx(p.dA1, A, 128, p.wt_f0, 128, p.dA2, 0, s));                       // d e
     TR_HIP(hipMemsetAsync(p.dz, 0, (size_t)Nn * 128 * sizeof(float), s));
     TR_RC(edgehip_pair_gather_add_bwd(p.dA2, 128, row, col, A, p.dz, stream));
     // node_out_mlp
     TR_RC(W.dw(p.dz, p.n2s, Nn, 128, 128, G->node_out_w4, G->node_out_b4));
-    TR_RC(tr_lin_dx(p.dz, Nn, 128, p.wt_no4, 128, p.dn, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.n2, p.dn, Nn * 128, p.dn, stream));
-    TR_RC(W.dw(p.dn, p.n1s, Nn, 128, 128, G->node_out_w2, G->node_out_b2));
-    TR_RC(tr_lin_dx(p.dn, Nn, 128, p.wt_no2, 128, p.dn2, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.n1, p.dn2, Nn * 128, p.dn2, stream));
-    TR_RC(W.dw(p.dn2, p.zin, Nn, 128, 256, G->node_out_w0, G->node_out_b0));
+    TR_RC(tr_lin_dx(p.dz, Nn, 128, p.wt_no4, 128, p.dn, 0, s, p.n2));
+        TR_RC(W.dw(p.dn, p.n1s, Nn, 128, 128, G->node_out_w2, G->node_out_b2));
+    TR_RC(tr_lin_dx(p.dn, Nn, 128, p.wt_no2, 128, p.dn2, 0, s, p.n1));
+        TR_RC(W.dw(p.dn2, p.zin, Nn, 128, 256, G->node_out_w0, G->node_out_b0));
     TR_RC(tr_lin_dx(p.dn2, Nn, 128, p.wt_no0, 256, p.dzin, 0, s));
     // zin = [h + cx | X0]
     float *dh = p.dh, *dh2 = p.dh2;
@@ -1164,9 +1176,8 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
         TR_RC(tr_global_bwd(G, p, i + 1, B, ds, W, stream));
         TR_RC(tr_segmean_bwd(L, ds, p.dnctx[i], 0, s));
         TR_RC(W.dw(p.dnctx[i], p.c1s[i], Nn, 64, 256, G->context_w2, G->context_b2));
-        TR_RC(tr_lin_dx(p.dnctx[i], Nn, 64, p.wt_c2, 256, p.dc1[i], 0, s));
-        TR_RC(edgehip_act_bwd(1, p.c1[i], p.dc1[i], Nn * 256, p.dc1[i], stream));
-        TR_RC(W.dw(p.dc1[i], p.cin[i], Nn, 256, 128, G->context_w0, G->context_b0));
+        TR_RC(tr_lin_dx(p.dnctx[i], Nn, 64, p.wt_c2, 256, p.dc1[i], 0, s, p.c1[i]));
+                TR_RC(W.dw(p.dc1[i], p.cin[i], Nn, 256, 128, G->context_w0, G->context_b0));
         TR_RC(tr_lin_dx(p.dc1[i], Nn, 256, p.wt_c0, 128, p.dcin[i], 0, s));          // d cin = [d h' | d cx[i] rows]
         TR_RC(tr_slice(Nn, p.dcin[i], 128, 0, 64, dh, 1, s));
         TR_RC(tr_segsum(L, p.dcin[i], 128, 64, ds, 1, s));
@@ -1175,11 +1186,10 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
         TR_RC(W.dw(p.dgi[i], p.xs[i], Nn, 192, 64, G->gru_w_ih, G->gru_b_ih));
         TR_RC(W.dw(p.dgh[i], p.hs[i], Nn, 192, 64, G->gru_w_hh, G->gru_b_hh));
         {
-            eh_gemm_desc ds[2] = {tr_desc_dx(p.dgi[i], Nn, 192, p.wt_ih, 64, p.dconv[i], 0),
+            eh_gemm_desc ds[2] = {tr_desc_dx(p.dgi[i], Nn, 192, p.wt_ih, 64, p.dconv[i], 0, p.conv[i]),   // through act{i}
                                   tr_desc_dx(p.dgh[i], Nn, 192, p.wt_hh, 64, dh2, 1)};
             TR_RC(eh_launch_gemm_group(ds, 2, s));
         }
-        TR_RC(edgehip_act_bwd(1, p.conv[i], p.dconv[i], Nn * 64, p.dconv[i], stream));
         // TransformerConv (layers.py:354)
         TR_RC(edgehip_attn_bwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.O[i], p.lse[i], p.dconv[i], p.Dbuf, p.dq[i], p.dk[i],
                                p.dv[i], stream));
@@ -1215,9 +1225,8 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
     // time mlp
     TR_RC(edgehip_act_bwd(2, p.m2, p.dmt, B * 64, p.dmt, stream));
     TR_RC(W.dw(p.dmt, p.m1s, B, 64, 256, G->mlp_w2, G->mlp_b2));
-    TR_RC(tr_lin_dx(p.dmt, B, 64, p.wt_mlp2, 256, p.dm1, 0, s));
-    TR_RC(edgehip_act_bwd(1, p.m1, p.dm1, B * 256, p.dm1, stream));
-    TR_RC(W.dw(p.dm1, p.pe, B, 256, 64, G->mlp_w0, G->mlp_b0));
+    TR_RC(tr_lin_dx(p.dmt, B, 64, p.wt_mlp2, 256, p.dm1, 0, s, p.m1));
+        TR_RC(W.dw(p.dm1, p.pe, B, 256, 64, G->mlp_w0, G->mlp_b0));
     return W.join();
 #undef GW
 }
