@@ -108,3 +108,63 @@ def test_two_rank_gradient_bucket_and_history_gather():
     for rank, ga, gb, gc, P, t_all, nb in got:
         assert torch.allclose(torch.tensor(ga), a0 + a1) and torch.allclose(torch.tensor(gb), b0)
         assert gc is None and P == 21.0 and t_all == [0, 1, 2, 3] and nb == 22
+
+
+def _arena_worker(rank, world, port, q):
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    from edgehip import shard, train
+    params = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7))]
+    arena = train.GradArena(params)
+    arena.zero_and_attach()
+    views_ok = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, arena.views))
+    # what the fused backward does: add straight into the views
+    params[0].grad += float(rank + 1)
+    params[1].grad += 10.0 * (rank + 1)
+    shard.allreduce_flat(arena.flat)
+    still = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, arena.views))
+    arena.zero_and_attach()
+    zeroed = float(arena.flat.abs().sum()) == 0.0 and arena.matches(params)
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, views_ok and still and zeroed, arena.flat.numel()))
+
+
+def _arena_values(rank, world, port, q):
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    from edgehip import shard, train
+    params = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7))]
+    arena = train.GradArena(params)
+    arena.zero_and_attach()
+    params[0].grad += float(rank + 1)
+    params[1].grad += 10.0 * (rank + 1)
+    shard.allreduce_flat(arena.flat)
+    td.barrier()
+    td.destroy_process_group()
+    q.put((rank, params[0].grad.tolist(), params[1].grad.tolist()))
+
+
+@pytest.mark.parametrize('worker', ['layout', 'values'])
+def test_two_rank_gradient_arena(worker):
+    """The flat gradient arena of the fused training step: p.grad are views, the all-reduce is in place."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    fn = _arena_worker if worker == 'layout' else _arena_values
+    ps = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in ps), key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for g in got:
+        if worker == 'layout':
+            assert g[1] is True and g[2] == 22
+        else:
+            assert g[1] == [[3.0] * 5] * 3 and g[2] == [30.0] * 7
