@@ -297,16 +297,19 @@ __global__ __launch_bounds__(64 * H) void k_tr_attn_fwd(edgehip_layout L, const 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int w0 = 0; w0 < row.words; w0 += 64) {
         const int n = tr_decode_chunk(row, w0, list, &cnt);
-        for (int e0 = 0; e0 < n; e0 += 4) {
-            const bool ok = e0 + slot < n;
-            const int64_t j = list[ok ? e0 + slot : e0];
-            const f32x4 kj = tr_ld4(K + j * HD + h * 64 + c4), vj = tr_ld4(V + j * HD + h * 64 + c4);
-            const float sc = tr_sum16(tr_dot4(q, kj)) * 0.125f;
-            if (ok) {
-                const float mn = fmaxf(m, sc);
-                const float r = expf(m - mn), pr = expf(sc - mn);
-                l = l * r + pr;
-                acc = acc * r + pr * vj;
+        for (int e0 = 0; e0 < n; e0 += 8) {                 // two neighbours per slot and trip: four row loads in flight
+            const bool oka = e0 + slot < n, okb = e0 + 4 + slot < n;
+            const int64_t ja = list[oka ? e0 + slot : e0], jb = list[okb ? e0 + 4 + slot : e0];
+            const f32x4 ka = tr_ld4(K + ja * HD + h * 64 + c4), va = tr_ld4(V + ja * HD + h * 64 + c4);
+            const f32x4 kb = tr_ld4(K + jb * HD + h * 64 + c4), vb = tr_ld4(V + jb * HD + h * 64 + c4);
+            const float sa = tr_sum16(tr_dot4(q, ka)) * 0.125f;
+            float sb = tr_sum16(tr_dot4(q, kb)) * 0.125f;
+            if (oka) {                                       // okb implies oka
+                sb = okb ? sb : -INFINITY;
+                const float mn = fmaxf(m, fmaxf(sa, sb));
+                const float r = expf(m - mn), pa = expf(sa - mn), pb = expf(sb - mn);
+                l = l * r + pa + pb;
+                acc = acc * r + pa * va + pb * vb;
                 m = mn;
             }
         }
@@ -361,13 +364,15 @@ __global__ __launch_bounds__(64 * H) void k_tr_attn_bwd_q(edgehip_layout L, cons
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     for (int w0 = 0; w0 < row.words; w0 += 64) {
         const int n = tr_decode_chunk(row, w0, list, &cnt);
-        for (int e0 = 0; e0 < n; e0 += 4) {
-            const bool ok = e0 + slot < n;
-            const int64_t j = list[ok ? e0 + slot : e0];
-            const f32x4 kj = tr_ld4(K + j * HD + h * 64 + c4), vj = tr_ld4(V + j * HD + h * 64 + c4);
-            const float sc = tr_sum16(tr_dot4(q, kj)) * 0.125f;
-            const float dov = tr_sum16(tr_dot4(go, vj));
-            if (ok) dq += (expf(sc - ls) * (dov - D) * 0.125f) * kj;
+        for (int e0 = 0; e0 < n; e0 += 8) {
+            const bool oka = e0 + slot < n, okb = e0 + 4 + slot < n;
+            const int64_t ja = list[oka ? e0 + slot : e0], jb = list[okb ? e0 + 4 + slot : e0];
+            const f32x4 ka = tr_ld4(K + ja * HD + h * 64 + c4), va = tr_ld4(V + ja * HD + h * 64 + c4);
+            const f32x4 kb = tr_ld4(K + jb * HD + h * 64 + c4), vb = tr_ld4(V + jb * HD + h * 64 + c4);
+            const float sa = tr_sum16(tr_dot4(q, ka)) * 0.125f, da = tr_sum16(tr_dot4(go, va));
+            const float sb = tr_sum16(tr_dot4(q, kb)) * 0.125f, db = tr_sum16(tr_dot4(go, vb));
+            if (oka) dq += (expf(sa - ls) * (da - D) * 0.125f) * ka;
+            if (okb) dq += (expf(sb - ls) * (db - D) * 0.125f) * kb;
         }
         __syncthreads();
     }
@@ -391,17 +396,23 @@ __global__ __launch_bounds__(64 * H) void k_tr_attn_bwd_kv(edgehip_layout L, con
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
     for (int w0 = 0; w0 < row.words; w0 += 64) {
         const int n = tr_decode_chunk(row, w0, list, &cnt);
-        for (int e0 = 0; e0 < n; e0 += 4) {
-            const bool ok = e0 + slot < n;
-            const int64_t i = list[ok ? e0 + slot : e0];
-            const f32x4 qi = tr_ld4(Q + i * HD + h * 64 + c4);
-            const f32x4 go = tr_ld4(dout + i * 64 + c4) * (1.0f / H);
-            const float sc = tr_sum16(tr_dot4(qi, kj)) * 0.125f;
-            const float dov = tr_sum16(tr_dot4(go, vj));
-            if (ok) {
-                const float a = expf(sc - lse[i * H + h]);
-                dk += (a * (dov - Dbuf[i * H + h]) * 0.125f) * qi;
-                dv += a * go;
+        for (int e0 = 0; e0 < n; e0 += 8) {
+            const bool oka = e0 + slot < n, okb = e0 + 4 + slot < n;
+            const int64_t ia = list[oka ? e0 + slot : e0], ib = list[okb ? e0 + 4 + slot : e0];
+            const f32x4 qa = tr_ld4(Q + ia * HD + h * 64 + c4), qb = tr_ld4(Q + ib * HD + h * 64 + c4);
+            const f32x4 ga = tr_ld4(dout + ia * 64 + c4) * (1.0f / H), gb = tr_ld4(dout + ib * 64 + c4) * (1.0f / H);
+            const float la = lse[ia * H + h], lb = lse[ib * H + h], Da = Dbuf[ia * H + h], Db = Dbuf[ib * H + h];
+            const float sa = tr_sum16(tr_dot4(qa, kj)) * 0.125f, da = tr_sum16(tr_dot4(ga, vj));
+            const float sb = tr_sum16(tr_dot4(qb, kj)) * 0.125f, db = tr_sum16(tr_dot4(gb, vj));
+            if (oka) {
+                const float a = expf(sa - la);
+                dk += (a * (da - Da) * 0.125f) * qa;
+                dv += a * ga;
+            }
+            if (okb) {
+                const float a = expf(sb - lb);
+                dk += (a * (db - Db) * 0.125f) * qb;
+                dv += a * gb;
             }
         }
         __syncthreads();

@@ -353,7 +353,8 @@ class BinomialDiffusionActive(nn.Module):
     def materialize_actives(self, batch):
         """Sets batch.active_node_indices / active_edge_indices (int64, ascending) like the reference."""
         st, L = batch._state, batch.layout
-        K, A = int(st['kptr'][-1].item()), int(st['aptr'][-1].item())
+        c = st['counts'].cpu().numpy().view(np.int32)       # edgehip_counts: k_total, pair_tiles, a_total (int64), ..: one sync
+        K, A = int(c[0]), int(c[2:4].view(np.int64)[0])
         ani = torch.empty(K, dtype=torch.int64, device=batch.device)
         aei = torch.empty(A, dtype=torch.int64, device=batch.device)
         row = torch.empty(A, dtype=torch.int64, device=batch.device)
@@ -440,10 +441,29 @@ class BinomialDiffusionActive(nn.Module):
         return batch
 
     # ---- a20 : time sampling ---------------------------------------------------------------
+    def _importance_ready(self):
+        """`(Lt_count > 10).all()` of diffusion_binomial_vanilla.py:250 without a device sync on every step:
+        the counts only grow, one per sampled t, so the test cannot pass before 11*T samples were added (a host
+        counter, seeded from the buffer once so that restored checkpoints count) and never fails again once it
+        has passed."""
+        if getattr(self, '_lt_ready', False):
+            return True
+        if getattr(self, '_lt_samples', None) is None:
+            self._lt_samples = int(self.Lt_count.sum().item())
+        if self._lt_samples < 11 * self.num_timesteps:
+            return False
+        ready = bool((self.Lt_count > 10).all())
+        self._lt_ready = ready
+        return ready
+
+    def load_state_dict(self, *args, **kwargs):
+        self._lt_ready, self._lt_samples = False, None      # Lt_count may change under us
+        return super().load_state_dict(*args, **kwargs)
+
     def _sample_time(self, b, device, method='uniform'):
         """diffusion_binomial_vanilla.py:248-269."""
         if method == 'importance':
-            if not (self.Lt_count > 10).all():
+            if not self._importance_ready():
                 return self._sample_time(b, device, method='uniform')
             Lt_sqrt = torch.sqrt(self.Lt_history + 1e-10) + 0.0001
             Lt_sqrt[0] = Lt_sqrt[1]
@@ -561,6 +581,8 @@ class BinomialDiffusionActive(nn.Module):
             prev = self.Lt_history.gather(dim=0, index=t_all)
             self.Lt_history.scatter_(dim=0, index=t_all, src=(0.1 * Lt2 + 0.9 * prev))
             self.Lt_count.scatter_add_(dim=0, index=t_all, src=torch.ones_like(Lt2))
+            if getattr(self, '_lt_samples', None) is not None:
+                self._lt_samples += int(t_all.numel())
         prior = self._kl_prior(batch).to(dev)
         vb = kl / pt + prior
         batch.num_entries = batch.num_pairs            # active.py:192-193

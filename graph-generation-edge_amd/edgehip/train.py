@@ -379,10 +379,17 @@ class _FusedNet(Function):
         nbytes = lib.edgehip_train_workspace_bytes(byref(L), byref(P), A)
         if nbytes == 0:
             raise capi.EdgeHipError('edgehip_train_workspace_bytes: unsupported configuration')
+        # the workspace carries the activations to the backward call: the batch keeps ONE for reuse across steps; a
+        # second forward before the first one's backward (two losses alive at once) gets a workspace of its own
         ws = getattr(batch, '_train_ws', None)
-        if ws is None or ws.numel() < nbytes:
+        busy = getattr(batch, '_train_ws_busy', False)
+        if busy:
+            ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=dev)
+        elif ws is None or ws.numel() < nbytes:
             ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
             batch._train_ws = ws
+        if not busy:
+            batch._train_ws_busy = True
         ce = torch.empty(B, dtype=torch.float32, device=dev)
         logits = torch.empty((A, 2), dtype=torch.float32, device=dev)
         d0 = batch.degree_i32
@@ -419,6 +426,8 @@ class _FusedNet(Function):
                                               d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
                                               capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(), ws.data_ptr(), ws.numel(),
                                               _s()), 'train_backward')
+        if ws is getattr(batch, '_train_ws', None):
+            batch._train_ws_busy = False
         head = (None,) * 10
         if direct:
             return head + (None,) * len(params)

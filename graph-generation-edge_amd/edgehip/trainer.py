@@ -28,6 +28,7 @@ def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=N
     backward adds into it, the data-parallel all-reduce runs on it in place and zeroing it is one memset."""
     from . import train
     model.train()
+    batch._train_ws_busy = False          # graphs of earlier steps are dead: their workspace is free again
     params = [p for p in model.parameters()]
     arena = None
     if state is not None and getattr(model, 'train_form', 'fused') == 'fused':
