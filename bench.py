@@ -119,6 +119,8 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--graphs', type=int, default=64, help='graphs sampled per GPU per step (num_generation)')
+    ap.add_argument('--parts', type=int, default=0,
+                    help='sub-batches (HIP streams) per sampling pass; 0 = the sampler default (3 for 64 graphs)')
     ap.add_argument('--train-steps', type=int, default=10, help='secondary metric: timed training steps (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -145,8 +147,10 @@ def main():
     assert count == B
     batch = edgehip.GraphBatch([n] * B, degree=[deg] * B, device=device, gid_base=gid_base)
 
-    def one_pass(i):
-        return model.sample_batch(batch, seed=1000 + i)
+    parts = a.parts if a.parts > 0 else model.default_parts(B)
+
+    def one_pass(i, parts=parts):
+        return model.sample_batch(batch, seed=1000 + i, parts=parts)
 
     def barrier():
         if dist:
@@ -171,20 +175,24 @@ def main():
            'config': {'workload': 'polblogs-shaped synthetic graph (n 1222, E 16714, d_max ~351; the pickle is never '
                                   'loaded), T=512 linear schedule, TGNN_degree_guided dim 64 heads 8/8/8/8/1 random '
                                   f'init, empirical d0, {B} generations per GPU per step', 'graphs_per_gpu': B,
-                      'diffusion_steps': T_STEPS, 'nodes_per_graph': n, 'sharding': f'sample-parallel x{world}'},
+                      'diffusion_steps': T_STEPS, 'nodes_per_graph': n, 'sharding': f'sample-parallel x{world}',
+                      'streams_per_gpu': parts},
            'mean_edges_per_sampled_graph': edges_out / B,
            'path_hbm': {'algorithmic_GB_per_graph': SURVEY_GB_PER_GRAPH,
                         'achieved_GBps_per_gpu': value / world * SURVEY_GB_PER_GRAPH,
                         'frac_of_hbm_peak': value / world * SURVEY_GB_PER_GRAPH / HBM_PEAK_GBPS}}
 
     if not a.no_roofline:
-        # one more pass of the same workload with HIP events around every launch (on the launch stream)
+        # one more pass of the same workload with HIP events around every launch (on the launch stream).  This pass
+        # runs the batch as ONE block of graphs on one stream: in the timed passes blocks of graphs overlap on
+        # several streams, and the duration of a launch that shares the chip with another stream's launches is
+        # not a property of the kernel (`python bench.py --parts 1` times that configuration end to end)
         import ctypes
         rows_done = ctypes.c_ulonglong(0)
         torch.cuda.synchronize()
         capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         capi.lib.edgehip_prof_enable(1)
-        one_pass(10 ** 6)
+        one_pass(10 ** 6, parts=1)
         torch.cuda.synchronize()
         capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         prof = capi.prof_collect()
@@ -209,6 +217,7 @@ def main():
                 roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBPS, 'traffic': None}
             roof['traffic'], roof['traffic_source'] = pmc_traffic(dom)
+            roof['measured'] = 'one extra pass, whole batch on one stream (kernel alone on the chip)'
             roof['avg_launch_us'] = kern[dom]['avg_us']
             roof['rows_per_launch'] = Nn
             roof['algorithmic_bytes_per_launch'] = by

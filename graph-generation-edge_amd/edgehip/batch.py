@@ -103,6 +103,34 @@ class GraphBatch:
     def new_adj(self):
         return torch.zeros_like(self.adj)
 
+    def split(self, parts):
+        """`parts` sub-batches over contiguous blocks of graphs that SHARE this batch's edge state (their `adj` are
+        views of `self.adj`; d0 is copied, it is constant).  Graph g of block k keeps its global id, so the
+        counter-based uniforms are those of the whole batch.  Used by the sampler to run blocks of graphs on
+        separate HIP streams; cached."""
+        cache = self.__dict__.setdefault('_split_cache', {})
+        if parts in cache:
+            return cache[parts]
+        B = self.num_graphs
+        parts = max(1, min(parts, B))
+        sizes = [B // parts + (1 if i < B % parts else 0) for i in range(parts)]
+        subs, g0 = [], 0
+        npg = self.host.nodes_per_graph
+        for k in sizes:
+            g1 = g0 + k
+            sub = GraphBatch(npg[g0:g1], degree=None, device=self.device, gid_base=int(self.layout.gid_base) + g0)
+            w0, w1 = int(self.host.adj_ptr[g0]), int(self.host.adj_ptr[g1])
+            n0, n1 = int(self.host.node_ptr[g0]), int(self.host.node_ptr[g1])
+            if w1 > w0:
+                sub.adj = self.adj[w0:w1]
+            if self.degree_i32 is not None:
+                sub.degree_i32 = self.degree_i32[n0:n1].clone()
+                sub.degree = self.degree[n0:n1].clone()
+            subs.append(sub)
+            g0 = g1
+        cache[parts] = subs
+        return subs
+
     def to(self, device):
         assert torch.device(device).type == self.device.type, 'GraphBatch is built on its device'
         return self

@@ -199,6 +199,29 @@ def test_fused_sampler_matches_stepwise_and_is_shard_invariant():
     assert torch.equal(b3.edge_index, b1.edge_index[:, sl[3]:] - off)
 
 
+@pytest.mark.parametrize('parts', [2, 3, 5])
+def test_sampler_on_sub_batch_streams_is_bit_identical(parts):
+    """sample_batch(parts=k): contiguous blocks of graphs on separate HIP streams sharing the batch's state;
+    graphs do not interact and the uniforms are keyed by global graph id, so the edge lists are those of the
+    single-stream run, bit for bit (ragged batch incl. 1-node, 2-node and empty graphs, block borders in between)."""
+    graphs = cases.ragged_graphs(3) + cases.ragged_graphs(4) + cases.ragged_graphs(5)[:5]
+    T, seed = 40, 1234
+    dmax = cases.max_degree_of(graphs)
+    model = H.build_model(orc.random_tgnn_params(5), T, dmax)
+    b1 = H.graph_batch(graphs, with_edges=False, gid_base=7)
+    model.sample_batch(b1, seed, parts=1)
+    bk = H.graph_batch(graphs, with_edges=False, gid_base=7)
+    model.sample_batch(bk, seed, parts=parts)
+    assert b1.edge_index.shape[1] > 50
+    assert torch.equal(b1.edge_index, bk.edge_index)
+    assert torch.equal(b1._slice_dict['edge_index'], bk._slice_dict['edge_index'])
+    # a second run on the same batch object reuses the cached sub-batches and streams
+    model.sample_batch(bk, seed + 1, parts=parts)
+    model.sample_batch(b1, seed + 1, parts=1)
+    assert torch.equal(b1.edge_index, bk.edge_index)
+    assert model.default_parts(64) == 3 and model.default_parts(7) == 1 and model.default_parts(16) == 2
+
+
 def test_sample_api_polblogs_shape():
     """model.sample(n) end to end at polblogs size (T shortened to 64 for test time): symmetric simple
     graph, ascending edge list, deterministic under a fixed seed."""
