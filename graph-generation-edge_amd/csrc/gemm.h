@@ -67,6 +67,74 @@ __device__ static inline void eh_load_frag_packed(eh_frag& f, const float* __res
     for (int i = 0; i < 8; ++i) f.v[i] = *reinterpret_cast<const f32x4*>(p + i * 256);
 }
 
+// ---- fp32 products on the bf16 matrix pipe ------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of v_mfma_f32_32x32x16_bf16.  An fp32 value splits EXACTLY
+// into three bf16 terms (x = h + m + l: 8 + 8 + 8 significant bits, by truncation), so the fp32 product sum
+// is the sum of nine bf16 product sums; the three smallest (m*l, l*m, l*l <= 2^-24 relative, below fp32
+// rounding) are dropped and six remain: 6 x 4 MFMAs of 32 cycles per 64-deep chunk instead of 32 of 64 cycles
+// (2.7x fewer matrix-pipe cycles), fp32 accumulation as before, and the SAME accumulator layout (eh_crow), so
+// epilogues are unchanged.  Measured error against fp64 is not larger than the fp32 instruction's.
+// Weights are split once (k_pack_w), activations per fragment (eh_split3: 5.5 vector ops per value).
+// Operand mapping: the bf16 instruction takes k = 8*(lane>>5) + j per lane; which physical k that is is free as
+// long as A and B agree, so group i (0..3) of a fragment feeds its k = 32*(lane>>5) + 8i + j.
+#ifndef EH_BF16X3
+#define EH_BF16X3 1
+#endif
+typedef __bf16 eh_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int eh_u32x4 __attribute__((ext_vector_type(4)));
+struct eh_frag3 { eh_u32x4 h[4], m[4], l[4]; };      // [i]: k-group 8i..8i+7 of the lane's 32 k, bf16 pairs in dwords
+
+__device__ static inline void eh_split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // upper halves: element 0 in the low 16 bits
+    pm = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ static inline void eh_split3(eh_frag3& o, const eh_frag& f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned ph, pm, pl;
+            eh_split_pair(f.v[2 * i + (p >> 1)][2 * (p & 1)], f.v[2 * i + (p >> 1)][2 * (p & 1) + 1], ph, pm, pl);
+            o.h[i][p] = ph; o.m[i][p] = pm; o.l[i][p] = pl;
+        }
+    }
+}
+#define EH_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(eh_bf16x8, A), __builtin_bit_cast(eh_bf16x8, B), C, 0, 0, 0)
+__device__ static inline void eh_mma64(f32x16& acc, const eh_frag3& a, const eh_frag3& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // small terms first
+        acc = EH_MFMA_BF16(a.l[i], b.h[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.l[i], acc);
+        acc = EH_MFMA_BF16(a.m[i], b.m[i], acc);
+        acc = EH_MFMA_BF16(a.m[i], b.h[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.m[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.h[i], acc);
+    }
+}
+// split weights in fragment order (k_pack_w): tile (nt, kc) = 3 planes (h, m, l) x [i = 0..3][lane][8 bf16];
+// 3072 float-sized words per tile, every load a coalesced 1-KiB row
+#define EH_PK_TILE 3072
+__device__ static inline void eh_load_frag_packed(eh_frag3& f, const float* __restrict__ packed, int KC, int nt, int kc,
+                                                  int lane) {
+    const eh_u32x4* p = reinterpret_cast<const eh_u32x4*>(packed + ((size_t)(nt * KC + kc) * EH_PK_TILE)) + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f.h[i] = p[i * 64]; f.m[i] = p[256 + i * 64]; f.l[i] = p[512 + i * 64]; }
+}
+#if EH_BF16X3
+typedef eh_frag3 eh_pfrag;                           // operands of a product with packed weights
+#define EH_PK_FLOATS(n) ((n) / 2 * 3)                // floats a packed [N][K] matrix occupies
+__device__ static inline void eh_to_pfrag(eh_pfrag& o, const eh_frag& f) { eh_split3(o, f); }
+#else
+typedef eh_frag eh_pfrag;
+#define EH_PK_FLOATS(n) (n)
+__device__ static inline void eh_to_pfrag(eh_pfrag& o, const eh_frag& f) { o = f; }
+#endif
+
 // Generic linear-layer descriptor (see gemm.hip)
 struct eh_gemm_desc {
     const float* A; int lda;            // A rows, k < K1
@@ -122,18 +190,22 @@ __device__ static inline void eh_gemm_packed_body(const eh_gemm_desc& d, int ng_
     const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
     const bool single = d.K == 64;
     eh_frag a;
-    if (single) eh_load_frag(a, ap);
+    eh_pfrag a3;
+    if (single) { eh_load_frag(a, ap); eh_to_pfrag(a3, a); }
     for (int ng = ng0; ng < ng1; ++ng) {
         f32x16 acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
         for (int kc = 0; kc < KC; ++kc) {
-            if (!single) eh_load_frag(a, (kc * 64 < d.K1) ? ap + kc * 64 : ap2 + (kc * 64 - d.K1));
+            if (!single) {
+                eh_load_frag(a, (kc * 64 < d.K1) ? ap + kc * 64 : ap2 + (kc * 64 - d.K1));
+                eh_to_pfrag(a3, a);
+            }
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
-                eh_frag b;
+                eh_pfrag b;
                 eh_load_frag_packed(b, d.W, KC, ng * NACC + j, kc, lane);
-                eh_mma64(acc[j], a, b);
+                eh_mma64(acc[j], a3, b);
             }
         }
 #pragma unroll

@@ -34,14 +34,15 @@ static eh_fold_map eh_make_fold_map(const edgehip_gnn_params* P) {
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
     m.nin_at = take(64); m.nin_a0 = take(64); m.nin_as = take(128);
     m.W4f = take(128 * 128); m.b4f = take(128);
-    m.pWih = take(192 * 64); m.pWhh = take(192 * 64); m.pCw0 = take(256 * 64);
-    m.pNo0 = take(128 * 256); m.pNo2 = take(128 * 128); m.pW4f = take(128 * 128); m.pFw2 = take(64 * 128);
+    m.pWih = take(EH_PK_FLOATS(192 * 64)); m.pWhh = take(EH_PK_FLOATS(192 * 64)); m.pCw0 = take(EH_PK_FLOATS(256 * 64));
+    m.pNo0 = take(EH_PK_FLOATS(128 * 256)); m.pNo2 = take(EH_PK_FLOATS(128 * 128)); m.pW4f = take(EH_PK_FLOATS(128 * 128));
+    m.pFw2 = take(EH_PK_FLOATS(64 * 128));
     for (int l = 0; l < P->num_layers && l < EDGEHIP_MAX_LAYERS; ++l) {
         size_t H = (size_t)P->heads[l] * EH_D;
         m.layer[l].Mcat = take(H * 64); m.layer[l].Mtcat = take(H * 64); m.layer[l].mbcat = take(H);
         m.layer[l].Ocat = take(64 * (H + 64)); m.layer[l].Vbbar = take(64 * 64); m.layer[l].bvbar = take(64);
         m.layer[l].Vsum = take(64 * 64);
-        m.layer[l].pMcat = take(H * 64); m.layer[l].pOcat = take(64 * (H + 64));
+        m.layer[l].pMcat = take(EH_PK_FLOATS(H * 64)); m.layer[l].pOcat = take(EH_PK_FLOATS(64 * (H + 64)));
     }
     m.te_table = take((size_t)P->num_steps * EDGEHIP_MAX_LAYERS * 64);
     m.total = o;
@@ -137,8 +138,31 @@ __global__ __launch_bounds__(128) void k_fold_tail(const float* __restrict__ f0,
     if (j == 0) b4f[i] = sb;
 }
 
-// Pack W[N][ldw] (columns col0 .. col0+K) into fragment order: tile (nt, kc) holds 32 rows x 64 k as
-// [i = 0..7][lane = 0..63][e = 0..3] = W[nt*32 + (lane&31)][col0 + kc*64 + (lane>>5)*32 + 4i + e].
+// Pack W[N][ldw] (columns col0 .. col0+K) into fragment order: tile (nt, kc) holds 32 rows x 64 k.
+//   fp32 form:   [i = 0..7][lane = 0..63][e = 0..3] = W[nt*32 + (lane&31)][col0 + kc*64 + (lane>>5)*32 + 4i + e]
+//   bf16x3 form: three planes (h, m, l of the exact split) of [i = 0..3][lane][j = 0..7] =
+//                W[nt*32 + (lane&31)][col0 + kc*64 + (lane>>5)*32 + 8i + j]           (gemm.h, eh_frag3)
+#if EH_BF16X3
+__global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, int ldw, int col0, int N, int K,
+                                                float* __restrict__ out) {
+    int idx = blockIdx.x * 256 + threadIdx.x;          // one 8-value group per thread
+    int total = N * K / 8;
+    if (idx >= total) return;
+    int lane = idx & 63, i = (idx >> 6) & 3, tile = idx >> 8;
+    int KC = K / 64;
+    int nt = tile / KC, kc = tile % KC;
+    const float* src = W + (size_t)(nt * 32 + (lane & 31)) * ldw + col0 + kc * 64 + (lane >> 5) * 32 + 8 * i;
+    eh_u32x4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned ph, pm, pl;
+        eh_split_pair(src[2 * p], src[2 * p + 1], ph, pm, pl);
+        h[p] = ph; m[p] = pm; l[p] = pl;
+    }
+    eh_u32x4* dst = reinterpret_cast<eh_u32x4*>(out + (size_t)tile * EH_PK_TILE) + lane;
+    dst[i * 64] = h; dst[256 + i * 64] = m; dst[512 + i * 64] = l;
+}
+#else
 __global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, int ldw, int col0, int N, int K,
                                                 float* __restrict__ out) {
     int idx = blockIdx.x * 256 + threadIdx.x;          // one float4 per thread
@@ -152,6 +176,7 @@ __global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, int
     v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
     *reinterpret_cast<f32x4*>(out + (size_t)idx * 4) = v;
 }
+#endif
 
 static void eh_pack(const float* W, int ldw, int col0, int N, int K, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_w, dim3((N * K / 4 + 255) / 256), dim3(256), 0, s, W, ldw, col0, N, K, out);
@@ -1047,10 +1072,12 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 
     // ---- phase A: qt
     if (anynbr) {
-        eh_frag af;
-        eh_load_frag_lds(af, hp, r, hh);
+        eh_frag af0;
+        eh_pfrag af;
+        eh_load_frag_lds(af0, hp, r, hh);
+        eh_to_pfrag(af, af0);
         for (int nt = wave; nt < 2 * HEADS; nt += 4) {
-            eh_frag bf;
+            eh_pfrag bf;
             eh_load_frag_packed(bf, a.Mcat, 1, nt, 0, lane);
             f32x16 acc = eh_zero16();
             eh_mma64(acc, af, bf);
@@ -1261,16 +1288,18 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         const int ch0 = kh ? SPLIT : 0, ch1 = kh ? NCH : SPLIT;
         f32x16 acc = eh_zero16();
         for (int ch = ch0; ch < ch1; ++ch) {
-            eh_frag af, bf;
+            eh_frag af0;
+            eh_pfrag af, bf;
             if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
             if (ch < HEADS) {
                 const float* p = qz + r * QP + ch * 64 + hh * 32;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+                for (int i = 0; i < 8; ++i) af0.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
             } else {
-                eh_load_frag_lds(af, hp, r, hh);
+                eh_load_frag_lds(af0, hp, r, hh);
             }
             eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, ch, lane);
+            eh_to_pfrag(af, af0);
             eh_mma64(acc, af, bf);
         }
         __syncthreads();                      // every wave is done reading qz
@@ -1302,9 +1331,12 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     {
         const int ct = wave & 1, part = wave >> 1;
         const int col = ct * 32 + r;
-        eh_frag am, ah, bf;
-        eh_load_frag_lds(am, mt, r, hh);
-        eh_load_frag_lds(ah, hp, r, hh);
+        eh_pfrag am, ah, bf;
+        {
+            eh_frag t0;
+            eh_load_frag_lds(t0, mt, r, hh); eh_to_pfrag(am, t0);
+            eh_load_frag_lds(t0, hp, r, hh); eh_to_pfrag(ah, t0);
+        }
         f32x16 g0 = eh_zero16(), g1 = eh_zero16();
         // gate biases requested before the products: part 1 -> (b_iz + b_hz, b_hn), part 0 -> (b_ir + b_hr, b_in)
         const float bA = a.b_ih[(part ? 64 : 0) + col] + a.b_hh[(part ? 64 : 0) + col];
@@ -1347,12 +1379,15 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 
     // ---- phase E: context pre-activation column sums
     {
-        eh_frag af;
-        eh_load_frag_lds(af, ht, r, hh);
+        eh_pfrag af;
+        {
+            eh_frag t0;
+            eh_load_frag_lds(t0, ht, r, hh); eh_to_pfrag(af, t0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int nt = wave * 2 + j;
-            eh_frag bf;
+            eh_pfrag bf;
             eh_load_frag_packed(bf, a.cw0, 1, nt, 0, lane);
             f32x16 acc = eh_zero16();
             eh_mma64(acc, af, bf);
@@ -1445,11 +1480,13 @@ __global__ __launch_bounds__(256) void k_tail(edgehip_layout L, edgehip_gnn_para
         f32x16 acc = eh_zero16();
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            eh_frag af, bf;
+            eh_frag af0;
+            eh_pfrag af, bf;
             const float* p = X + r * EH_XP + kc * 64 + hh * 32;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            for (int i = 0; i < 8; ++i) af0.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
             eh_load_frag_packed(bf, pNo0, 4, wave, kc, lane);
+            eh_to_pfrag(af, af0);
             eh_mma64(acc, af, bf);
         }
         const float bb = P.node_out_b0[col];
@@ -1461,11 +1498,13 @@ __global__ __launch_bounds__(256) void k_tail(edgehip_layout L, edgehip_gnn_para
         f32x16 acc = eh_zero16();
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            eh_frag af, bf;
+            eh_frag af0;
+            eh_pfrag af, bf;
             const float* p = U1 + r * EH_UP + kc * 64 + hh * 32;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            for (int i = 0; i < 8; ++i) af0.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
             eh_load_frag_packed(bf, pNo2, 2, wave, kc, lane);
+            eh_to_pfrag(af, af0);
             eh_mma64(acc, af, bf);
         }
         const float bb = P.node_out_b2[col];
@@ -1477,11 +1516,13 @@ __global__ __launch_bounds__(256) void k_tail(edgehip_layout L, edgehip_gnn_para
         f32x16 acc = eh_zero16();
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            eh_frag af, bf;
+            eh_frag af0;
+            eh_pfrag af, bf;
             const float* p = U2 + r * EH_UP + kc * 64 + hh * 32;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            for (int i = 0; i < 8; ++i) af0.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
             eh_load_frag_packed(bf, pW4f, 2, wave, kc, lane);
+            eh_to_pfrag(af, af0);
             eh_mma64(acc, af, bf);
         }
         const float bb = b4f[col];
