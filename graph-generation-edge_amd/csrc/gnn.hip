@@ -1658,6 +1658,7 @@ struct eh_pair_args {
     const float* node_repr; const int32_t* act_nodes; const int32_t* kptr; const int64_t* aptr; const int32_t* tptr;
     edgehip_counts* counts;
     const float *fb0, *fw2, *fb2, *fw4, *fb4;
+    const float* pfw2;           // final_out.2 in fragment order (folded buffer)
     const float* logits_in; int logits_are_logprobs;
     const float* uniforms; edgehip_rng rng; int use_rng; int step; const float* lut;
     uint32_t* adj;               // MODE 0: state (rw); MODE 1: x_{t-1} (ro)
@@ -1707,9 +1708,10 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) e.v[i][c] = eh_silu_fast(fa.v[i][c] + fb.v[i][c] + fc.v[i][c]);
-                eh_frag w;
-                eh_load_frag(w, a.fw2 + (size_t)r * 128 + ko);        eh_mma64(acc0, e, w);
-                eh_load_frag(w, a.fw2 + (size_t)(32 + r) * 128 + ko); eh_mma64(acc1, e, w);
+                eh_pfrag e3, w;
+                eh_to_pfrag(e3, e);
+                eh_load_frag_packed(w, a.pfw2, 2, 0, ch, lane); eh_mma64(acc0, e3, w);
+                eh_load_frag_packed(w, a.pfw2, 2, 1, ch, lane); eh_mma64(acc1, e3, w);
             }
             const float b20 = a.fb2[r], b21 = a.fb2[32 + r];
 #pragma unroll
@@ -1799,8 +1801,9 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
     }
 }
 
-static void eh_fill_pair_weights(eh_pair_args& a, const edgehip_gnn_params* P) {
+static void eh_fill_pair_weights(eh_pair_args& a, const edgehip_gnn_params* P, const float* folded) {
     a.fb0 = P->final_b0; a.fw2 = P->final_w2; a.fb2 = P->final_b2; a.fw4 = P->final_w4; a.fb4 = P->final_b4;
+    a.pfw2 = folded ? folded + eh_make_fold_map(P).pFw2 : nullptr;
 }
 
 extern "C" int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
@@ -1809,15 +1812,14 @@ extern "C" int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_
                                      const float* logits_in, int32_t logits_are_logprobs, const float* uniforms,
                                      const edgehip_rng* rng, int32_t step, const float* gumbel_lut, uint32_t* adj,
                                      float* logits_out, uint8_t* bits_out, int64_t pair_cap, void* stream) {
-    (void)folded;
     EH_CHECK_ARG(L && act_nodes && kptr && aptr && tptr && counts && adj);
     EH_CHECK_ARG(uniforms || rng);
-    EH_CHECK_ARG(logits_in || (node_repr && P));
+    EH_CHECK_ARG(logits_in || (node_repr && P && folded));
     if (!logits_in) { int rc = eh_check_params(P); if (rc != EDGEHIP_OK) return rc; }
     if (L->num_graphs == 0) return EDGEHIP_OK;
     eh_pair_args a = {};
     a.node_repr = node_repr; a.act_nodes = act_nodes; a.kptr = kptr; a.aptr = aptr; a.tptr = tptr; a.counts = counts;
-    if (P) eh_fill_pair_weights(a, P);
+    if (P) eh_fill_pair_weights(a, P, folded);
     a.logits_in = logits_in; a.logits_are_logprobs = logits_are_logprobs;
     a.uniforms = uniforms; a.rng = rng ? *rng : edgehip_rng{0}; a.use_rng = uniforms ? 0 : 1; a.step = step;
     a.lut = gumbel_lut; a.adj = adj; a.logits_out = logits_out; a.bits_out = bits_out; a.pair_cap = pair_cap;
@@ -1847,14 +1849,14 @@ extern "C" int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_p
                                     const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
                                     const uint32_t* adj_tm1, float* tile_partial, int64_t tile_cap, float* kl,
                                     float* logits_out, int64_t pair_cap, void* stream) {
-    (void)folded;
     int rc = eh_check_params(P);
     if (rc != EDGEHIP_OK) return rc;
+    EH_CHECK_ARG(folded);
     EH_CHECK_ARG(L && node_repr && act_nodes && kptr && aptr && tptr && counts && adj_tm1 && tile_partial && kl);
     if (L->num_graphs == 0) return EDGEHIP_OK;
     eh_pair_args a = {};
     a.node_repr = node_repr; a.act_nodes = act_nodes; a.kptr = kptr; a.aptr = aptr; a.tptr = tptr; a.counts = counts;
-    eh_fill_pair_weights(a, P);
+    eh_fill_pair_weights(a, P, folded);
     a.adj = const_cast<uint32_t*>(adj_tm1); a.logits_out = logits_out; a.pair_cap = pair_cap;
     a.tile_partial = tile_partial; a.tile_cap = tile_cap;
     EH_PROF(EH_K_PAIR, eh_stream(stream), hipLaunchKernelGGL(k_pair<1>, dim3(2048), dim3(256), 0, eh_stream(stream), *L, a));

@@ -299,8 +299,14 @@ def test_train_step_matches_oracle_adam_and_learns(arena):
     losses = [float(edgehip.train_step(model, b, opt, clip_value=1.0, **kw))]
     # Adam's first step moves every weight by lr * g / (|g| + 1e-8): where |g| ~ 1e-8 the step amplifies the
     # rounding noise of g, so the bound is 5% of lr element-wise and 0.1% of lr on average
+    gmax = max(float(r.grad.abs().max()) for r in po.values() if r.grad is not None)
     for k, v in model._denoise_fn.named_parameters():
         d = (v.detach().cpu() - po[k].detach()).abs()
+        if po[k].grad is None or float(po[k].grad.abs().max()) < 1e-6 * gmax:
+            # a gradient that is zero in exact arithmetic (the key bias: softmax is shift-invariant) is rounding noise
+            # on both sides, and Adam turns noise of any size into a step of up to lr: only that bound holds
+            assert float(d.max()) <= 1.1e-3, (k, float(d.max()))
+            continue
         assert float(d.max()) < 5e-5 and float(d.mean()) < 1e-6, (k, float(d.max()), float(d.mean()))
     for _ in range(5):
         losses.append(float(edgehip.train_step(model, b, opt, clip_value=1.0, **kw)))
