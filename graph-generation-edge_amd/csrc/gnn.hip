@@ -550,7 +550,9 @@ __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld
 
 // grid (B, EH_GU_PARTS): every part recomputes the (cheap) context chain, then takes its share of the
 // per-graph bias vectors of layer l, so that 4 x B blocks are in flight instead of B.
+#ifndef EH_GU_PARTS
 #define EH_GU_PARTS 4
+#endif
 struct eh_update_args {
     int l; eh_layer_ptrs lp;
     const float* part; const float* te; const int32_t* t_graph; int te_shared;
@@ -627,8 +629,8 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
         eh_block_gemv<64, true>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
     }
     {   // cbias = context_b0 + context_w0[:, 64:128] . ctx             64 rows per part
-        eh_block_gemv<64, false>(P.context_w0 + 64, 128, cn, nullptr, 0, nullptr, P.context_b0, prt * 64, 64,
-                                 cbias + (size_t)g * 256, 0);
+        eh_block_gemv<64, false>(P.context_w0 + 64, 128, cn, nullptr, 0, nullptr, P.context_b0, prt * (256 / EH_GU_PARTS),
+                                 256 / EH_GU_PARTS, cbias + (size_t)g * 256, 0);
     }
     if (prt == 1)       // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx
         eh_block_gemv<64, true>(lp.skip_w + 64, 128, tev, lp.skip_w, 128, xc, lp.skip_b, 0, 64, obias0 + (size_t)g * 64, 0);
