@@ -609,7 +609,10 @@ extern "C" int edgehip_linear_bwd_weight(const float* dY, const float* X, int64_
     EH_CHECK_ARG(dY && X && dW && M >= 0 && N > 0 && K > 0);
     if (M == 0) return EDGEHIP_OK;
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
-    int64_t want = (2048 + tiles - 1) / tiles;                       // blocks along M for ~2048 blocks in all
+#ifndef TR_TN_BLOCKS
+#define TR_TN_BLOCKS 512
+#endif
+    int64_t want = (TR_TN_BLOCKS + tiles - 1) / tiles;               // blocks along M for ~TR_TN_BLOCKS blocks in all
     int64_t rpb = (M + want - 1) / want;
     rpb = ((rpb + 63) / 64) * 64;                                    // 4 waves x multiple of 16 rows
     if (rpb < 64) rpb = 64;
