@@ -168,7 +168,7 @@ __global__ void k_tr_assemble_fwd(int Nn, const int32_t* node_graph, const float
 // column sums of src[rows of graph g][col0 .. col0+64) ADDED into out[g][64] (scaled): blockIdx.y = graph,
 // blockIdx.x = chunk of TR_SEG_ROWS rows, one float atomic per (block, column); `out` is zero-filled (or holds
 // the value to accumulate onto) before the launch.  One block per graph left 4 blocks on 256 CUs (70 us).
-#define TR_SEG_ROWS 128
+#define TR_SEG_ROWS 32
 __global__ __launch_bounds__(256) void k_tr_segment_sum(const int32_t* node_ptr, const float* src, int ld, int col0,
                                                         const float* add, int mean, float* out) {
     __shared__ float part[4][64];
@@ -201,6 +201,17 @@ __global__ void k_tr_slice(int64_t M, const float* src, int ld, int col0, int nc
     int c = (int)(idx % ncol);
     float v = src[i * ld + col0 + c];
     dst[idx] = acc ? dst[idx] + v : v;
+}
+
+// a += b + c + d  (float4 per thread)
+__global__ void k_tr_add4(int64_t n4, float* a, const float* b, const float* c, const float* d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 va = reinterpret_cast<f32x4*>(a)[i];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i], vc = reinterpret_cast<const f32x4*>(c)[i],
+                vd = reinterpret_cast<const f32x4*>(d)[i];
+    va += vb + vc + vd;
+    reinterpret_cast<f32x4*>(a)[i] = va;
 }
 
 // dx[i][c] (+)= dout[g(i)][c] / n_g
@@ -855,7 +866,7 @@ struct tr_plan {
     float *dnctx[EDGEHIP_MAX_LAYERS], *dc1[EDGEHIP_MAX_LAYERS], *dcin[EDGEHIP_MAX_LAYERS], *dgi[EDGEHIP_MAX_LAYERS];
     float *dgh[EDGEHIP_MAX_LAYERS], *dconv[EDGEHIP_MAX_LAYERS], *dq[EDGEHIP_MAX_LAYERS], *dk[EDGEHIP_MAX_LAYERS];
     float *dv[EDGEHIP_MAX_LAYERS], *dx[EDGEHIP_MAX_LAYERS], *dtl[EDGEHIP_MAX_LAYERS];
-    float *dmt, *dm1, *dgin0;
+    float *dmt, *dm1, *dgin0, *dxp;
     size_t floats;
 };
 
@@ -902,6 +913,7 @@ static void tr_make_plan(tr_plan& p, const edgehip_layout* L, const edgehip_gnn_
         p.dx[i] = b.take(Nn * 128); p.dtl[i] = b.take(B * 64);
     }
     p.dmt = b.take(B * 64); p.dm1 = b.take(B * 256); p.dgin0 = b.take(B * 64);
+    p.dxp = b.take(Nn * 128 * 3);
     p.floats = b.off;
 }
 
@@ -1211,13 +1223,17 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
         TR_RC(W.dw(p.dk[i], p.x[i], Nn, hd, 128, G->key_w[i], G->key_b[i]));
         TR_RC(W.dw(p.dv[i], p.x[i], Nn, hd, 128, G->value_w[i], G->value_b[i]));
         TR_RC(W.dw(p.dconv[i], p.x[i], Nn, 64, 128, G->skip_w[i], G->skip_b[i]));
-        {   // the four input-gradient products meet in dx (float atomics onto a zero-filled buffer), one launch
-            TR_HIP(hipMemsetAsync(p.dx[i], 0, (size_t)Nn * 128 * sizeof(float), s));
-            eh_gemm_desc ds[4] = {tr_desc_dx(p.dq[i], Nn, hd, p.wt_q[i], 128, p.dx[i], 2),
-                                  tr_desc_dx(p.dk[i], Nn, hd, p.wt_k[i], 128, p.dx[i], 2),
-                                  tr_desc_dx(p.dv[i], Nn, hd, p.wt_v[i], 128, p.dx[i], 2),
-                                  tr_desc_dx(p.dconv[i], Nn, 64, p.wt_sk[i], 128, p.dx[i], 2)};
+        {   // the four input-gradient products in one launch, each into its own buffer, then one pass adds them
+            // (float atomics onto a shared dx were 2.5 M atomics per layer: slower than the products themselves)
+            float* part1 = p.dxp, *part2 = p.dxp + (size_t)Nn * 128, *part3 = p.dxp + (size_t)Nn * 256;
+            eh_gemm_desc ds[4] = {tr_desc_dx(p.dq[i], Nn, hd, p.wt_q[i], 128, p.dx[i], 0),
+                                  tr_desc_dx(p.dk[i], Nn, hd, p.wt_k[i], 128, part1, 0),
+                                  tr_desc_dx(p.dv[i], Nn, hd, p.wt_v[i], 128, part2, 0),
+                                  tr_desc_dx(p.dconv[i], Nn, 64, p.wt_sk[i], 128, part3, 0)};
             TR_RC(eh_launch_gemm_group(ds, 4, s));
+            const int64_t n4 = Nn * 32;
+            EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_add4, TR_GRID(n4, 256), dim3(256), 0, s, n4, p.dx[i], part1, part2, part3));
+            EH_LAUNCH_CHECK();
         }
         // x = [h + cx (i > 0) | tl_g]
         TR_RC(tr_slice(Nn, p.dx[i], 128, 0, 64, dh2, 1, s));
