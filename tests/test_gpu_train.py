@@ -316,3 +316,68 @@ def test_train_step_matches_oracle_adam_and_learns(arena):
     with torch.no_grad():
         nv = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
     assert abs(float(-nv.sum() / (np.log(2) * P)) - losses[-1]) < 0.2 * abs(losses[0] - losses[-1]) + 1e-3
+
+
+def test_fused_and_op_forms_agree_and_two_live_forwards():
+    """The one-node form (edgehip_train_forward/_backward) against the node-per-op form on a ragged batch with
+    shared (t, uniforms): same loss, same gradients to float-atomic noise; a second forward on the same batch
+    before the first backward gets a workspace of its own (both backwards still correct)."""
+    graphs = cases.ragged_graphs(7) + cases.ragged_graphs(8)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(11)
+    rng = np.random.default_rng(5)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    u1, u3 = cases.uniforms(rng, P, 2).cuda(), cases.uniforms(rng, P, 2).cuda()
+    t = torch.tensor([5, 9, 3, 20, 1, 13] * 2)
+    pt = torch.full((len(graphs),), 1.0 / T)
+    grads = {}
+    for form in ('ops', 'fused'):
+        model = H.build_model(params, T, dmax)
+        model.train()
+        model.train_form = form
+        b = H.graph_batch(graphs, degree_dtype=np.int64)
+        nv = model.log_prob(b, t, pt, u1, u3)
+        if form == 'fused':
+            nv_b = model.log_prob(b, t, pt, u1, u3)           # second live forward on the same batch object
+            assert torch.allclose(nv, nv_b, rtol=1e-6, atol=1e-9)
+        (-nv.sum() / (np.log(2) * b.num_entries)).backward()
+        grads[form] = {k: v.grad.detach().clone() for k, v in model._denoise_fn.named_parameters() if v.grad is not None}
+        grads[form + '_nv'] = nv.detach().clone()
+        if form == 'fused':
+            for v in model._denoise_fn.parameters():
+                v.grad = None
+            (-nv_b.sum() / (np.log(2) * b.num_entries)).backward()
+            grads['fused_b'] = {k: v.grad.detach().clone() for k, v in model._denoise_fn.named_parameters() if v.grad is not None}
+    assert torch.allclose(grads['ops_nv'], grads['fused_nv'], rtol=1e-5, atol=1e-9)
+    gmax = max(float(g.abs().max()) for g in grads['ops'].values())
+    assert gmax > 0
+    for k, g in grads['ops'].items():
+        scale = max(float(g.abs().max()), 1e-6 * gmax)
+        for other in ('fused', 'fused_b'):
+            err = float((grads[other][k] - g).abs().max()) / scale
+            assert err < 2e-4, (k, other, err)
+
+
+def test_train_entry_points_reject_bad_arguments():
+    from edgehip import capi
+    graphs = cases.ragged_graphs(3)
+    model = H.build_model(orc.random_tgnn_params(5), 48, cases.max_degree_of(graphs))
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    Pm = model._denoise_fn.raw_params()
+    need = capi.lib.edgehip_train_workspace_bytes(C.byref(b.layout), C.byref(Pm), 10)
+    assert need > 0 and capi.lib.edgehip_train_workspace_bytes(C.byref(b.layout), C.byref(Pm), -1) == 0
+    z = torch.zeros(64, device='cuda')
+    zi = torch.zeros(b.num_nodes + 32, dtype=torch.int32, device='cuda')
+    zb = torch.zeros(b.num_nodes + 32, dtype=torch.uint8, device='cuda')
+    tg = torch.zeros(b.num_graphs, dtype=torch.int32, device='cuda')
+    ws = torch.empty(1024, dtype=torch.uint8, device='cuda')
+    rc = capi.lib.edgehip_train_forward(C.byref(b.layout), C.byref(Pm), b.adj.data_ptr(), zi.data_ptr(), b.degree_i32.data_ptr(),
+                                        zb.data_ptr(), tg.data_ptr(), None, None, 0, None, None, z.data_ptr(), None,
+                                        ws.data_ptr(), ws.numel(), capi.stream_ptr())
+    assert rc == capi.ERR_WORKSPACE
+    rc = capi.lib.edgehip_train_forward(C.byref(b.layout), C.byref(Pm), None, zi.data_ptr(), b.degree_i32.data_ptr(),
+                                        zb.data_ptr(), tg.data_ptr(), None, None, 0, None, None, z.data_ptr(), None,
+                                        ws.data_ptr(), ws.numel(), capi.stream_ptr())
+    assert rc == capi.ERR_ARG
+    torch.cuda.synchronize()
