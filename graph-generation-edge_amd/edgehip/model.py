@@ -447,13 +447,15 @@ class BinomialDiffusionActive(nn.Module):
             # stream beyond them shares a queue with another one (measured: 82.6 graphs/s with 4 side streams)
             streams = [cur] + self._streams(dev, len(subs) - 1)
             work = []
-            for b, st in zip(subs, streams):
-                if st is not cur:
-                    st.wait_stream(cur)      # tables / folded weights were produced on the current stream
+            # every buffer of the blocks is allocated (and zero-filled) on the current stream BEFORE the side streams
+            # are ordered behind it: a fill queued later on `cur` could land on top of a block's first step
+            prepared = [(_state(b)['counts'], _workspace(b, P)) for b in subs]
+            for st in streams[1:]:
+                st.wait_stream(cur)          # also: tables / folded weights were produced on the current stream
+            for b, st, (counts, ws) in zip(subs, streams, prepared):
                 with torch.cuda.stream(st):
-                    ws = _workspace(b, P)
                     b.adj.zero_()
-                work.append((byref(b.layout), b.adj.data_ptr(), b.degree_i32.data_ptr(), _state(b)['counts'].data_ptr(),
+                work.append((byref(b.layout), b.adj.data_ptr(), b.degree_i32.data_ptr(), counts.data_ptr(),
                              ws.data_ptr(), ws.numel(), st.cuda_stream))
         for t in reversed(range(self.num_timesteps)):
             for (Lr, adj, d0, counts, ws, wsn, s) in work:
