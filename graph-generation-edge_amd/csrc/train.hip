@@ -5,6 +5,7 @@
 // Batches are small here (polblogs: 4 graphs), so the ops favour plain, checkable kernels.
 #include "common.h"
 #include "gemm.h"
+#include "gemv.h"
 #include "prof.h"
 
 #define TR_D 64
@@ -1014,10 +1015,54 @@ static int tr_segmean_bwd(const edgehip_layout* L, const float* dout, float* dx,
     return EDGEHIP_OK;
 }
 
+// global_mlp on the B per-graph rows as ONE launch each way (block per graph, block-cooperative GEMVs of gemv.h):
+// as MFMA products these were two launches of a single 4-row tile each, 9-13 us of pure latency apiece.
+__global__ __launch_bounds__(256) void k_tr_global_fwd(const float* __restrict__ gin, const float* __restrict__ W0,
+                                                       const float* __restrict__ b0, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, float* __restrict__ g1,
+                                                       float* __restrict__ g1s, float* __restrict__ cx) {
+    __shared__ __attribute__((aligned(16))) float v[64], pre[256], hid[256], out[64];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) v[tid] = gin[(size_t)g * 64 + tid];
+    __syncthreads();
+    eh_block_gemv<64, false>(W0, 64, v, nullptr, 0, nullptr, b0, 0, 256, pre, 0);
+    __syncthreads();
+    {
+        const float x = pre[tid], y = tr_act(1, x);
+        g1[(size_t)g * 256 + tid] = x; g1s[(size_t)g * 256 + tid] = y; hid[tid] = y;
+    }
+    __syncthreads();
+    eh_block_gemv<256, false>(W2, 256, hid, nullptr, 0, nullptr, b2, 0, 64, out, 0);
+    __syncthreads();
+    if (tid < 64) cx[(size_t)g * 64 + tid] = out[tid];
+}
+// d cx -> d g1 (pre-activation gradient, kept for the weight-gradient product) -> d gin; WT2 = W2^T [256,64], WT0 = W0^T [64,256]
+__global__ __launch_bounds__(256) void k_tr_global_bwd(const float* __restrict__ dcx, const float* __restrict__ g1,
+                                                       const float* __restrict__ WT2, const float* __restrict__ WT0,
+                                                       float* __restrict__ dg1, float* __restrict__ dgin) {
+    __shared__ __attribute__((aligned(16))) float v[64], pre[256], hid[256], out[64];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) v[tid] = dcx[(size_t)g * 64 + tid];
+    __syncthreads();
+    eh_block_gemv<64, false>(WT2, 64, v, nullptr, 0, nullptr, nullptr, 0, 256, pre, 0);
+    __syncthreads();
+    {
+        const float d = pre[tid] * tr_act_grad(1, g1[(size_t)g * 256 + tid]);
+        dg1[(size_t)g * 256 + tid] = d; hid[tid] = d;
+    }
+    __syncthreads();
+    eh_block_gemv<256, false>(WT0, 256, hid, nullptr, 0, nullptr, nullptr, 0, 64, out, 0);
+    __syncthreads();
+    if (tid < 64) dgin[(size_t)g * 64 + tid] = out[tid];
+}
+
 // global_mlp(gin) -> cx   (layers.py:343,368)
 static int tr_global_fwd(const edgehip_gnn_params* P, const tr_plan& p, int j, int64_t B, hipStream_t s) {
-    TR_RC(tr_lin(p.gin[j], B, 64, P->global_w0, P->global_b0, 256, p.g1[j], p.g1s[j], s));
-    return tr_lin(p.g1s[j], B, 256, P->global_w2, P->global_b2, 64, p.cx[j], nullptr, s);
+    if (B == 0) return EDGEHIP_OK;
+    EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_global_fwd, dim3((unsigned)B), dim3(256), 0, s, p.gin[j], P->global_w0,
+                       P->global_b0, P->global_w2, P->global_b2, p.g1[j], p.g1s[j], p.cx[j]));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
 }
 // Side stream for the weight-gradient products.  Nothing on the main stream waits for dW/db until the step ends,
 // so they are queued on a second HIP stream behind an event of the launch that produced their dY and overlap
@@ -1066,9 +1111,12 @@ static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, i
     hipStream_t s = eh_stream(st);
     const float* dcx = p.dcxj[j];
     TR_RC(W.dw(dcx, p.g1s[j], B, 64, 256, G->global_w2, G->global_b2));
-    TR_RC(tr_lin_dx(dcx, B, 64, p.wt_g2, 256, p.dg1[j], 0, s, p.g1[j]));
-        TR_RC(W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0));
-    return tr_lin_dx(p.dg1[j], B, 256, p.wt_g0, 64, ds, 0, s);
+    if (B > 0) {
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_global_bwd, dim3((unsigned)B), dim3(256), 0, s, dcx, p.g1[j], p.wt_g2, p.wt_g0,
+                           p.dg1[j], ds));
+        EH_LAUNCH_CHECK();
+    }
+    return W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0);
 }
 
 extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
@@ -1240,8 +1288,13 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
         if (i > 0) TR_RC(tr_segsum(L, p.dx[i], 128, 0, ds, 1, s));
         TR_RC(tr_segsum(L, p.dx[i], 128, 64, p.dtl[i], 0, s));
         TR_RC(W.dw(p.dtl[i], p.mt, B, 64, 64, G->time_w[i], G->time_b[i]));
-        TR_RC(tr_lin_dx(p.dtl[i], B, 64, p.wt_time[i], 64, p.dmt, i != nl - 1, s));
         float* t0 = dh; dh = dh2; dh2 = t0;
+    }
+    {   // d mt = sum_i d tl_i W_time_i: the per-layer products are independent, one grouped launch (atomics onto zero)
+        TR_HIP(hipMemsetAsync(p.dmt, 0, (size_t)B * 64 * sizeof(float), s));
+        eh_gemm_desc ds[EDGEHIP_MAX_LAYERS];
+        for (int i = 0; i < nl; ++i) ds[i] = tr_desc_dx(p.dtl[i], B, 64, p.wt_time[i], 64, p.dmt, 2);
+        TR_RC(eh_launch_gemm_group(ds, nl, s));
     }
     // first context, node_in, embeddings
     float* dgin0 = p.dgin0;
