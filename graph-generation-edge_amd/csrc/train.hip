@@ -189,6 +189,29 @@ __global__ __launch_bounds__(256) void k_tr_segment_sum(const int32_t* node_ptr,
         atomicAdd(out + g * 64 + c, s);
     }
 }
+// backward of `assemble` for a [Nn,128] gradient in ONE launch: dh[i] += src[i][:64], sumA[g] += column sums of
+// src[:, :64] (optional), sumB[g] += column sums of src[:, 64:] (both onto zero-filled / running buffers)
+__global__ __launch_bounds__(256) void k_tr_assemble_bwd128(const int32_t* node_ptr, const float* __restrict__ src,
+                                                            float* __restrict__ dh, float* sumA, float* sumB) {
+    __shared__ float pa[4][64], pb[4][64];
+    const int g = blockIdx.y, c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int i0 = node_ptr[g], i1 = node_ptr[g + 1];
+    const int a = i0 + (int)blockIdx.x * TR_SEG_ROWS;
+    if (a >= i1) return;
+    const int b = a + TR_SEG_ROWS < i1 ? a + TR_SEG_ROWS : i1;
+    float sa = 0.f, sb = 0.f;
+    for (int i = a + r; i < b; i += 4) {
+        const float va = src[(int64_t)i * 128 + c], vb = src[(int64_t)i * 128 + 64 + c];
+        dh[(int64_t)i * 64 + c] += va;
+        sa += va; sb += vb;
+    }
+    pa[r][c] = sa; pb[r][c] = sb;
+    __syncthreads();
+    if (r == 0) {
+        if (sumA) atomicAdd(sumA + g * 64 + c, pa[0][c] + pa[1][c] + pa[2][c] + pa[3][c]);
+        atomicAdd(sumB + g * 64 + c, pb[0][c] + pb[1][c] + pb[2][c] + pb[3][c]);
+    }
+}
 static inline dim3 tr_seg_grid(const edgehip_layout* L) {
     int chunks = (L->max_nodes + TR_SEG_ROWS - 1) / TR_SEG_ROWS;
     return dim3(chunks < 1 ? 1 : chunks, L->num_graphs);
@@ -1253,8 +1276,9 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
         TR_RC(tr_lin_dx(p.dnctx[i], Nn, 64, p.wt_c2, 256, p.dc1[i], 0, s, p.c1[i]));
                 TR_RC(W.dw(p.dc1[i], p.cin[i], Nn, 256, 128, G->context_w0, G->context_b0));
         TR_RC(tr_lin_dx(p.dc1[i], Nn, 256, p.wt_c0, 128, p.dcin[i], 0, s));          // d cin = [d h' | d cx[i] rows]
-        TR_RC(tr_slice(Nn, p.dcin[i], 128, 0, 64, dh, 1, s));
-        TR_RC(tr_segsum(L, p.dcin[i], 128, 64, ds, 1, s));
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_assemble_bwd128, tr_seg_grid(L), dim3(256), 0, s, L->node_ptr, p.dcin[i], dh,
+                           (float*)nullptr, ds));
+        EH_LAUNCH_CHECK();
         // GRU (layers.py:360)
         TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], p.hs[i], dh, Nn, p.dgi[i], p.dgh[i], dh2, stream));
         TR_RC(W.dw(p.dgi[i], p.xs[i], Nn, 192, 64, G->gru_w_ih, G->gru_b_ih));
@@ -1284,9 +1308,10 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
             EH_LAUNCH_CHECK();
         }
         // x = [h + cx (i > 0) | tl_g]
-        TR_RC(tr_slice(Nn, p.dx[i], 128, 0, 64, dh2, 1, s));
-        if (i > 0) TR_RC(tr_segsum(L, p.dx[i], 128, 0, ds, 1, s));
-        TR_RC(tr_segsum(L, p.dx[i], 128, 64, p.dtl[i], 0, s));
+        TR_HIP(hipMemsetAsync(p.dtl[i], 0, (size_t)B * 64 * sizeof(float), s));
+        EH_PROF(EH_K_TRAIN, s, hipLaunchKernelGGL(k_tr_assemble_bwd128, tr_seg_grid(L), dim3(256), 0, s, L->node_ptr, p.dx[i], dh2,
+                           i > 0 ? ds : (float*)nullptr, p.dtl[i]));
+        EH_LAUNCH_CHECK();
         TR_RC(W.dw(p.dtl[i], p.mt, B, 64, 64, G->time_w[i], G->time_b[i]));
         float* t0 = dh; dh = dh2; dh2 = t0;
     }
