@@ -801,7 +801,10 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
                                                     float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
-    __shared__ uint32_t list[2048 + 16];           // a 64-word chunk holds at most 2048 neighbours (+ step padding)
+#ifndef EH_HCHUNK
+#define EH_HCHUNK 64                   // bit-row words decoded per chunk (<= 64: one word per lane)
+#endif
+    __shared__ uint32_t list[32 * EH_HCHUNK + 16];  // a chunk holds at most 32 * EH_HCHUNK neighbours (+ step padding)
     const int lane = threadIdx.x;
     const int nheavy = *counter;
     const int grp = lane / EH_LG, c = lane % EH_LG;
@@ -841,8 +844,8 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] += qb[d]; acc[d] = f32x2{0.f, 0.f}; }
             eh_scale_q_log2e(q);
         }
-        for (int w0 = 0; w0 < stride; w0 += 64) {
-            uint32_t w = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+        for (int w0 = 0; w0 < stride; w0 += EH_HCHUNK) {
+            uint32_t w = (lane < EH_HCHUNK && w0 + lane < stride) ? rowp[w0 + lane] : 0u;
             const int cnt = __popc(w);
             int incl = cnt;
 #pragma unroll
