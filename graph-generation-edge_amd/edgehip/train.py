@@ -371,7 +371,11 @@ class use_arena:
 
 class _FusedNet(Function):
     @staticmethod
-    def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, *params):
+    def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, arena_params, *inputs):
+        # arena_params: the parameters when their gradients go straight into the active GradArena; `inputs` is then a
+        # single anchor tensor (autograd only has to call backward: an apply() over 86 parameter inputs costs ~0.25 ms
+        # of host time each way, right after the step's only host sync).  Otherwise `inputs` are the parameters.
+        params = arena_params if arena_params is not None else inputs
         L = batch.layout
         P = net.raw_params()
         A, B = row.numel(), batch.num_graphs
@@ -397,16 +401,18 @@ class _FusedNet(Function):
                                              flags.data_ptr(), t_graph.data_ptr(), capi.ptr(row), capi.ptr(col), A,
                                              capi.ptr(tgt), capi.ptr(pair_graph), ce.data_ptr(), logits.data_ptr(),
                                              ws.data_ptr(), ws.numel(), _s()), 'train_forward')
-        ctx.args = (net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params)
+        ctx.args = (net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params, arena_params is not None)
         ctx.mark_non_differentiable(logits)
         return ce, logits
 
     @staticmethod
     def backward(ctx, gce, _glogits):
-        net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params = ctx.args
+        net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params, anchored = ctx.args
         L = batch.layout
         arena = _ACTIVE_ARENA[0]
         direct = arena is not None and arena.matches(params)
+        if anchored and not direct:
+            raise capi.EdgeHipError('the gradient arena of this forward is no longer active (backward outside use_arena)')
         if direct:
             grads = None
             address = lambda p: arena.grad_of(p).data_ptr()
@@ -428,9 +434,9 @@ class _FusedNet(Function):
                                               _s()), 'train_backward')
         if ws is getattr(batch, '_train_ws', None):
             batch._train_ws_busy = False
-        head = (None,) * 10
+        head = (None,) * 11
         if direct:
-            return head + (None,) * len(params)
+            return head + (None,) * (1 if anchored else len(params))
         used = {prm.data_ptr() for _, _, prm in net.param_slots()}
         return head + tuple(g if p.data_ptr() in used else None for p, g in zip(params, grads))
 
@@ -441,4 +447,11 @@ def tgnn_ce_fused(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_
     if len(params) != sum(1 for _ in net.parameters()):
         # frozen parameters: the op-by-op form lets autograd skip them
         return tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph)
-    return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, *params)
+    arena = _ACTIVE_ARENA[0]
+    if arena is not None and arena.matches(params):
+        anchor = getattr(net, '_grad_anchor', None)
+        if anchor is None or anchor.device != adj_t.device:
+            anchor = net._grad_anchor = torch.zeros((), device=adj_t.device, requires_grad=True)
+        return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph,
+                               tuple(params), anchor)
+    return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, None, *params)
