@@ -67,6 +67,17 @@ def sum_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def sum_over_ranks_device(value, device):
+    """As sum_over_ranks, but the result stays on the device (0-d fp32 tensor) when a process group is up: the
+    training step divides by it without a host sync.  Without a group: the python number."""
+    td = _dist()
+    if td is None:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t[0].to(torch.float32)
+
+
 def all_gather_cat(x):
     """Concatenation of every rank's 1-D tensor in rank order (equal lengths): the (t, kl) pairs every
     replica must apply to Lt_history / Lt_count so the importance sampler stays identical across ranks

@@ -40,7 +40,7 @@ def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=N
         optimizer.zero_grad(set_to_none=True)
     with train.use_arena(arena):
         neg_vb = model.log_prob(batch, **log_prob_kwargs)                   # [B], differentiable
-        P = shard.sum_over_ranks(batch.num_entries, batch.device)
+        P = shard.sum_over_ranks_device(batch.num_entries, batch.device)   # global pair count, no host sync
         loss = -neg_vb.sum() / (math.log(2) * P)                            # diffusion/loss.py:10-12
         loss.backward()
     if arena is not None:

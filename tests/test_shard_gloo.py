@@ -85,6 +85,8 @@ def _train_worker(rank, world, port, q):
     params[2].requires_grad_(False)
     bucket = shard.allreduce_gradients(params)
     P = shard.sum_over_ranks(10 + rank)
+    Pd = shard.sum_over_ranks_device(10 + rank, 'cpu')
+    assert torch.is_tensor(Pd) and Pd.dtype == torch.float32 and float(Pd) == P
     t_all = shard.all_gather_cat(torch.tensor([rank * 2, rank * 2 + 1]))
     td.barrier()
     td.destroy_process_group()
