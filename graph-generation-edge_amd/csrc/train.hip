@@ -1142,22 +1142,20 @@ static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, i
     return W.dw(p.dg1[j], p.gin[j], B, 256, 64, G->global_w0, G->global_b0);
 }
 
-extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
-                                     const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
-                                     const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
-                                     const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
-                                     void* stream) {
-    EH_CHECK_ARG(L && P && adj_t && deg_t && d0 && flags && t_graph && ce_graph && ws && A >= 0);
-    EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph && logits));
+// node part of the forward: everything up to the per-node output z.  It needs no active pairs, only a CAPACITY A_cap
+// that fixes the workspace layout; a caller can queue it before it knows how many pairs the step has.
+static int tr_forward_nodes(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t, const int32_t* deg_t,
+                            const int32_t* d0, const uint8_t* flags, const int32_t* t_graph, int64_t A_cap, void* ws,
+                            size_t ws_bytes, void* stream) {
+    EH_CHECK_ARG(L && P && adj_t && deg_t && d0 && flags && t_graph && ws && A_cap >= 0);
     TR_RC(tr_check_net(P));
-    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A)) return EDGEHIP_ERR_WORKSPACE;
+    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A_cap)) return EDGEHIP_ERR_WORKSPACE;
     hipStream_t s = eh_stream(stream);
     const int64_t Nn = L->num_nodes, B = L->num_graphs;
     const int nl = P->num_layers;
-    TR_HIP(hipMemsetAsync(ce_graph, 0, (size_t)B * sizeof(float), s));
     if (Nn == 0 || B == 0) return EDGEHIP_OK;
     tr_plan p;
-    tr_make_plan(p, L, P, A, tr_ws_base(ws));
+    tr_make_plan(p, L, P, A_cap, tr_ws_base(ws));
     // input embeddings, node_in (layers.py:326-336)
     TR_RC(edgehip_train_embed_fwd(L, deg_t, d0, flags, P->max_degree, P->embedding_t_w, P->embedding_t_b, P->embedding_0_w,
                                   P->embedding_0_b, P->embedding_sel_w, p.X0, stream));
@@ -1202,28 +1200,73 @@ extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_
     TR_RC(edgehip_assemble_fwd(L, p.hs[nl], p.cx[nl], nullptr, p.X0, 192, p.zin, stream));
     TR_RC(tr_lin(p.zin, Nn, 256, P->node_out_w0, P->node_out_b0, 128, p.n1, p.n1s, s));
     TR_RC(tr_lin(p.n1s, Nn, 128, P->node_out_w2, P->node_out_b2, 128, p.n2, p.n2s, s));
-    TR_RC(tr_lin(p.n2s, Nn, 128, P->node_out_w4, P->node_out_b4, 128, p.z, nullptr, s));
-    if (A == 0) return EDGEHIP_OK;
+    return tr_lin(p.n2s, Nn, 128, P->node_out_w4, P->node_out_b4, 128, p.z, nullptr, s);
+}
+
+// pair part: gather of the active pairs, final_out, CE (layers.py:380-381, active.py:157-175); A <= A_cap
+static int tr_forward_pairs(const edgehip_layout* L, const edgehip_gnn_params* P, const int64_t* row, const int64_t* col,
+                            int64_t A, int64_t A_cap, const uint8_t* tgt, const int32_t* pair_graph, float* ce_graph,
+                            float* logits, void* ws, size_t ws_bytes, void* stream) {
+    EH_CHECK_ARG(L && P && ce_graph && ws && A >= 0 && A <= A_cap);
+    EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph && logits));
+    TR_RC(tr_check_net(P));
+    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A_cap)) return EDGEHIP_ERR_WORKSPACE;
+    hipStream_t s = eh_stream(stream);
+    TR_HIP(hipMemsetAsync(ce_graph, 0, (size_t)L->num_graphs * sizeof(float), s));
+    if (L->num_nodes == 0 || L->num_graphs == 0 || A == 0) return EDGEHIP_OK;
+    tr_plan p;
+    tr_make_plan(p, L, P, A_cap, tr_ws_base(ws));
     TR_RC(edgehip_pair_gather_add_fwd(p.z, 128, row, col, A, p.e, stream));
     TR_RC(tr_lin(p.e, A, 128, P->final_w0, P->final_b0, 128, p.f1, p.f1s, s));
     TR_RC(tr_lin(p.f1s, A, 128, P->final_w2, P->final_b2, 64, p.f2, p.f2s, s));
     return edgehip_edge_ce_fwd(p.f2s, P->final_w4, P->final_b4, tgt, pair_graph, A, logits, ce_graph, stream);
 }
 
+extern "C" int edgehip_train_forward_nodes(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                           const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                           const int32_t* t_graph, int64_t A_cap, void* ws, size_t ws_bytes, void* stream) {
+    return tr_forward_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, A_cap, ws, ws_bytes, stream);
+}
+extern "C" int edgehip_train_forward_pairs(const edgehip_layout* L, const edgehip_gnn_params* P, const int64_t* row,
+                                           const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                                           const int32_t* pair_graph, float* ce_graph, float* logits, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return tr_forward_pairs(L, P, row, col, A, A_cap, tgt, pair_graph, ce_graph, logits, ws, ws_bytes, stream);
+}
+extern "C" int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                     const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
+                                     const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
+                                     const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    EH_CHECK_ARG(ce_graph && A >= 0);
+    TR_RC(tr_forward_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, A, ws, ws_bytes, stream));
+    return tr_forward_pairs(L, P, row, col, A, A, tgt, pair_graph, ce_graph, logits, ws, ws_bytes, stream);
+}
+
+extern "C" int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                                          const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                          const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                                          const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream);
 extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
                                       const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                                       const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
                                       const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream) {
-    EH_CHECK_ARG(L && P && G && adj_t && deg_t && d0 && flags && gce && ws && A >= 0);
+    return edgehip_train_backward_cap(L, P, G, adj_t, deg_t, d0, flags, row, col, A, A, tgt, pair_graph, gce, ws, ws_bytes, stream);
+}
+extern "C" int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                                          const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                          const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                                          const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream) {
+    EH_CHECK_ARG(L && P && G && adj_t && deg_t && d0 && flags && gce && ws && A >= 0 && A <= A_cap);
     EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph));
     TR_RC(tr_check_net(P));
-    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A)) return EDGEHIP_ERR_WORKSPACE;
+    if (ws_bytes < edgehip_train_workspace_bytes(L, P, A_cap)) return EDGEHIP_ERR_WORKSPACE;
     hipStream_t s = eh_stream(stream);
     const int64_t Nn = L->num_nodes, B = L->num_graphs;
     const int nl = P->num_layers;
     if (Nn == 0 || B == 0 || A == 0) return EDGEHIP_OK;          // no active pair: the loss does not depend on the network
     tr_plan p;
-    tr_make_plan(p, L, P, A, tr_ws_base(ws));
+    tr_make_plan(p, L, P, A_cap, tr_ws_base(ws));
 #define GW(f) ((float*)G->f)
     {   // weights transposed once per call, all in one launch (dX = dY W runs as a linear layer on W^T)
         tr_tlist tl = {};

@@ -103,6 +103,11 @@ EXPORTS = {
                               vp, vp, C.c_size_t, vp],
     'edgehip_train_backward': [C.POINTER(Layout), C.POINTER(GnnParams), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp,
                                C.c_int64, vp, vp, vp, vp, C.c_size_t, vp],
+    'edgehip_train_forward_nodes': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, C.c_int64, vp, C.c_size_t, vp],
+    'edgehip_train_forward_pairs': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp,
+                                    C.c_size_t, vp],
+    'edgehip_train_backward_cap': [C.POINTER(Layout), C.POINTER(GnnParams), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp,
+                                   C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_size_t, vp],
 }
 SIZE_EXPORTS = {
     'edgehip_gnn_folded_floats': [C.POINTER(GnnParams)],

@@ -350,11 +350,32 @@ class BinomialDiffusionActive(nn.Module):
                                                    st['aptr'].data_ptr(), st['tptr'].data_ptr(),
                                                    st['counts'].data_ptr(), capi.stream_ptr()), 'active_offsets')
 
-    def materialize_actives(self, batch):
+    def _read_counts(self, batch, after=None):
+        """(K, A) of the step from the device-side edgehip_counts.  With `after` (an event recorded right behind the
+        offsets kernel) the copy runs on a side stream behind that event into pinned memory, so the host does not
+        wait for work queued on the current stream AFTER the event (the node part of the training forward)."""
+        st = batch._state
+        if after is None:
+            c = st['counts'].cpu().numpy().view(np.int32)   # edgehip_counts: k_total, pair_tiles, a_total (int64), ..: one sync
+        else:
+            dev = batch.device
+            rb = self.__dict__.setdefault('_rb', {}).get(str(dev))
+            if rb is None:
+                rb = self._rb[str(dev)] = (torch.cuda.Stream(device=dev), torch.empty(8, dtype=torch.int32).pin_memory(),
+                                           torch.cuda.Event())
+            stream, pinned, done = rb
+            stream.wait_event(after)
+            with torch.cuda.stream(stream):
+                pinned.copy_(st['counts'], non_blocking=True)
+                done.record(stream)
+            done.synchronize()
+            c = pinned.numpy().copy().view(np.int32)
+        return int(c[0]), int(c[2:4].view(np.int64)[0])
+
+    def materialize_actives(self, batch, counts=None):
         """Sets batch.active_node_indices / active_edge_indices (int64, ascending) like the reference."""
         st, L = batch._state, batch.layout
-        c = st['counts'].cpu().numpy().view(np.int32)       # edgehip_counts: k_total, pair_tiles, a_total (int64), ..: one sync
-        K, A = int(c[0]), int(c[2:4].view(np.int64)[0])
+        K, A = self._read_counts(batch) if counts is None else counts
         ani = torch.empty(K, dtype=torch.int64, device=batch.device)
         aei = torch.empty(A, dtype=torch.int64, device=batch.device)
         row = torch.empty(A, dtype=torch.int64, device=batch.device)
@@ -589,7 +610,15 @@ class BinomialDiffusionActive(nn.Module):
             from . import train
             if net._pos_emb is None or net._pos_emb.device != dev:
                 net._pos_emb = tables.pos_emb_table(net.num_steps, net.dim).to(dev)
-            self.materialize_actives(batch)
+            counts = None
+            if getattr(self, 'train_form', 'fused') != 'ops':
+                # the node part of the network needs no active pairs: it is queued before the step's only host sync
+                # (the pair counts), read back on a side stream behind the offsets kernel
+                after = torch.cuda.Event()
+                after.record(torch.cuda.current_stream(dev))
+                train.prelaunch_nodes(net, batch, adj_t, st['deg_t'], st['flags'], t_graph)
+                counts = self._read_counts(batch, after)
+            self.materialize_actives(batch, counts)
             row, col = batch.active_row, batch.active_col
             tgt, pair_graph = train.pair_targets(batch, adj_tm1, row, col)
             fwd = train.tgnn_ce_forward if getattr(self, 'train_form', 'fused') == 'ops' else train.tgnn_ce_fused

@@ -369,6 +369,40 @@ class use_arena:
         _ACTIVE_ARENA[0] = self.prev
 
 
+def _take_workspace(batch, L, P, cap, dev):
+    """The batch keeps ONE workspace for reuse across steps; a forward that finds it busy (a second loss alive before
+    the first one's backward) gets a workspace of its own."""
+    nbytes = lib.edgehip_train_workspace_bytes(byref(L), byref(P), cap)
+    if nbytes == 0:
+        raise capi.EdgeHipError('edgehip_train_workspace_bytes: unsupported configuration')
+    ws = getattr(batch, '_train_ws', None)
+    if getattr(batch, '_train_ws_busy', False):
+        return torch.empty(nbytes + 4096, dtype=torch.uint8, device=dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=dev)
+        batch._train_ws = ws
+    batch._train_ws_busy = True
+    return ws
+
+
+def prelaunch_nodes(net, batch, adj_t, deg_t, flags, t_graph):
+    """Queues the node part of the fused forward NOW, before the caller has read the number of active pairs back
+    from the device (the step's only host sync): the device works through it while the host enumerates the pairs.
+    Needs the pair capacity of an earlier step on this batch; returns False (nothing queued) without one."""
+    cap = getattr(batch, '_train_cap', 0)
+    if cap <= 0 or getattr(batch, '_train_ws_busy', False) or '_train_pre' in batch.__dict__:
+        return False
+    if not all(p.requires_grad for p in net.parameters()):
+        return False
+    L, P = batch.layout, net.raw_params()
+    ws = _take_workspace(batch, L, P, cap, adj_t.device)
+    capi.check(lib.edgehip_train_forward_nodes(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(),
+                                               batch.degree_i32.data_ptr(), flags.data_ptr(), t_graph.data_ptr(), cap,
+                                               ws.data_ptr(), ws.numel(), _s()), 'train_forward_nodes')
+    batch._train_pre = dict(ws=ws, cap=cap, adj=adj_t.data_ptr())
+    return True
+
+
 class _FusedNet(Function):
     @staticmethod
     def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, arena_params, *inputs):
@@ -380,27 +414,30 @@ class _FusedNet(Function):
         P = net.raw_params()
         A, B = row.numel(), batch.num_graphs
         dev = adj_t.device
-        nbytes = lib.edgehip_train_workspace_bytes(byref(L), byref(P), A)
-        if nbytes == 0:
-            raise capi.EdgeHipError('edgehip_train_workspace_bytes: unsupported configuration')
-        # the workspace carries the activations to the backward call: the batch keeps ONE for reuse across steps; a
-        # second forward before the first one's backward (two losses alive at once) gets a workspace of its own
-        ws = getattr(batch, '_train_ws', None)
-        busy = getattr(batch, '_train_ws_busy', False)
-        if busy:
-            ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=dev)
-        elif ws is None or ws.numel() < nbytes:
-            ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
-            batch._train_ws = ws
-        if not busy:
-            batch._train_ws_busy = True
+        d0 = batch.degree_i32
         ce = torch.empty(B, dtype=torch.float32, device=dev)
         logits = torch.empty((A, 2), dtype=torch.float32, device=dev)
-        d0 = batch.degree_i32
-        capi.check(lib.edgehip_train_forward(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
-                                             flags.data_ptr(), t_graph.data_ptr(), capi.ptr(row), capi.ptr(col), A,
-                                             capi.ptr(tgt), capi.ptr(pair_graph), ce.data_ptr(), logits.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), _s()), 'train_forward')
+        pre = batch.__dict__.pop('_train_pre', None)
+        if pre is not None and (A > pre['cap'] or pre['adj'] != adj_t.data_ptr()):
+            if pre['ws'] is getattr(batch, '_train_ws', None):
+                batch._train_ws_busy = False              # the node part queued ahead does not fit this step: redo it
+            pre = None
+        if pre is not None:
+            ws, cap = pre['ws'], pre['cap']
+        else:
+            # the workspace layout is fixed by a CAPACITY of active pairs that only grows, so that the node part of the
+            # next step can be queued (prelaunch_nodes) before that step's pair count is known
+            cap = getattr(batch, '_train_cap', 0)
+            if A > cap:
+                cap = batch._train_cap = int(A * 1.3) + 4096
+            ws = _take_workspace(batch, L, P, cap, dev)
+            capi.check(lib.edgehip_train_forward_nodes(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
+                                                       flags.data_ptr(), t_graph.data_ptr(), cap, ws.data_ptr(), ws.numel(),
+                                                       _s()), 'train_forward_nodes')
+        capi.check(lib.edgehip_train_forward_pairs(byref(L), byref(P), capi.ptr(row), capi.ptr(col), A, cap, capi.ptr(tgt),
+                                                   capi.ptr(pair_graph), ce.data_ptr(), logits.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _s()), 'train_forward_pairs')
+        ctx.cap = cap
         ctx.args = (net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params, arena_params is not None)
         ctx.mark_non_differentiable(logits)
         return ce, logits
@@ -428,10 +465,10 @@ class _FusedNet(Function):
         G = capi.GnnParams()
         net.fill_struct(G, address)
         gce = gce.contiguous()
-        capi.check(lib.edgehip_train_backward(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
-                                              d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
-                                              capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              _s()), 'train_backward')
+        capi.check(lib.edgehip_train_backward_cap(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
+                                                  d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
+                                                  ctx.cap, capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), _s()), 'train_backward')
         if ws is getattr(batch, '_train_ws', None):
             batch._train_ws_busy = False
         head = (None,) * 11

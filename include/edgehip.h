@@ -337,6 +337,21 @@ int edgehip_train_forward(const edgehip_layout* L, const edgehip_gnn_params* P, 
                           const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
                           const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
                           void* stream);
+/* The same step in three calls for callers that queue work before they know the number of active pairs: the node
+ * part (everything up to the per-node output) only needs a CAPACITY A_cap >= A that fixes the workspace layout
+ * (edgehip_train_workspace_bytes(L,P,A_cap)); the pair part and the backward then take the real A and the same
+ * A_cap.  edgehip_train_forward / _backward are these with A_cap = A. */
+int edgehip_train_forward_nodes(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
+                                int64_t A_cap, void* ws, size_t ws_bytes, void* stream);
+int edgehip_train_forward_pairs(const edgehip_layout* L, const edgehip_gnn_params* P, const int64_t* row,
+                                const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                                const int32_t* pair_graph, float* ce_graph, float* logits, void* ws, size_t ws_bytes,
+                                void* stream);
+int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                               const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                               const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                               const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream);
 int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
                            const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                            const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
