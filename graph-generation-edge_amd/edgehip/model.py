@@ -173,19 +173,27 @@ class TGNN_degree_guided(nn.Module):
             else:
                 getattr(P, field)[layer] = address_of(prm)
 
+    def pos_emb(self, dev):
+        """The sinusoid table on `dev`, built once ('cuda' and 'cuda:0' name the same device: compare resolved
+        indices, or the table would be rebuilt per call and cached structs would keep the freed one's address)."""
+        dev = torch.device(dev)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        if self._pos_emb is None or self._pos_emb.device != dev:
+            self._pos_emb = tables.pos_emb_table(self.num_steps, self.dim).to(dev)
+        return self._pos_emb
+
     def raw_params(self):
         """GnnParams over the raw parameters only (no folding): what the training calls read."""
         dev = self.embedding_t.weight.device
         if dev.type != 'cuda':
             raise capi.EdgeHipError('the model must live on a GPU (model.to("cuda")); there is no CPU path')
         ps = list(self.parameters())
-        key = (dev, tuple(p.data_ptr() for p in ps))
+        key = (dev, tuple(p.data_ptr() for p in ps), self.pos_emb(dev).data_ptr())
         if getattr(self, '_raw_key', None) == key:
             return self._raw
         for p in ps:
             assert p.dtype == torch.float32 and p.is_contiguous()
-        if self._pos_emb is None or self._pos_emb.device != dev:
-            self._pos_emb = tables.pos_emb_table(self.num_steps, self.dim).to(dev)
         P = capi.GnnParams()
         P.dim, P.num_layers, P.max_degree, P.num_steps = self.dim, len(self.num_heads), int(self.max_degree), self.num_steps
         for i, h in enumerate(self.num_heads):
@@ -201,13 +209,11 @@ class TGNN_degree_guided(nn.Module):
         if dev.type != 'cuda':
             raise capi.EdgeHipError('the model must live on a GPU (model.to("cuda")); there is no CPU path')
         ps = list(self.parameters())
-        key = (dev, tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps))
+        key = (dev, tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps), self.pos_emb(dev).data_ptr())
         if key == self._folded_key:
             return self._cparams, self._folded
         for p in ps:
             assert p.dtype == torch.float32 and p.is_contiguous()
-        if self._pos_emb is None or self._pos_emb.device != dev:
-            self._pos_emb = tables.pos_emb_table(self.num_steps, self.dim).to(dev)
         P = capi.GnnParams()
         P.dim, P.num_layers, P.max_degree, P.num_steps = self.dim, len(self.num_heads), int(self.max_degree), self.num_steps
         for i, h in enumerate(self.num_heads):
@@ -608,8 +614,7 @@ class BinomialDiffusionActive(nn.Module):
         net = self._denoise_fn
         if differentiable:
             from . import train
-            if net._pos_emb is None or net._pos_emb.device != dev:
-                net._pos_emb = tables.pos_emb_table(net.num_steps, net.dim).to(dev)
+            net.pos_emb(dev)
             counts = None
             if getattr(self, 'train_form', 'fused') != 'ops':
                 # the node part of the network needs no active pairs: it is queued before the step's only host sync

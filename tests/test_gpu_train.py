@@ -381,3 +381,55 @@ def test_train_entry_points_reject_bad_arguments():
                                         ws.data_ptr(), ws.numel(), capi.stream_ptr())
     assert rc == capi.ERR_ARG
     torch.cuda.synchronize()
+
+
+def test_prelaunched_node_part_hit_and_miss_give_the_same_gradients():
+    """Steps on ONE batch object with different t: the node part of the forward is queued ahead of the pair-count
+    readback from the second step on (capacity of the earlier steps); a step with more active pairs than that
+    capacity discards the queued part and redoes it.  Every step's loss and gradients equal those of a fresh batch
+    (no prelaunch) on the same (t, uniforms)."""
+    graphs = cases.ragged_graphs(7) + cases.ragged_graphs(9)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(13)
+    rng = np.random.default_rng(8)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    u1, u3 = cases.uniforms(rng, P, 2).cuda(), cases.uniforms(rng, P, 2).cuda()
+    pt = torch.full((len(graphs),), 1.0 / T)
+    model = H.build_model(params, T, dmax)
+    model.train()
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    seen = []
+    for t_val in (40, 40, 3, 20, 1):          # few active pairs first, then many (capacity miss), then fewer again
+        t = torch.full((len(graphs),), t_val)
+        for v in model._denoise_fn.parameters():
+            v.grad = None
+        if t_val == 20:
+            b._train_cap = 16                 # these graphs never outgrow a real capacity: force the miss
+        want = {}
+        nv = model.log_prob(b, t, pt, u1, u3, want)
+        seen.append((int(want['logits'].shape[0]), getattr(b, '_train_cap', 0)))
+        (-nv.sum() / (np.log(2) * b.num_entries)).backward()
+        got = {k: v.grad.detach().clone() for k, v in model._denoise_fn.named_parameters() if v.grad is not None}
+        ref_model = H.build_model(params, T, dmax)
+        ref_model.train()
+        fb = H.graph_batch(graphs, degree_dtype=np.int64)
+        nv2 = ref_model.log_prob(fb, t, pt, u1, u3)
+        (-nv2.sum() / (np.log(2) * fb.num_entries)).backward()
+        assert torch.allclose(nv.detach(), nv2.detach(), rtol=1e-5, atol=1e-9), t_val
+        ref = {k: v.grad for k, v in ref_model._denoise_fn.named_parameters() if v.grad is not None}
+        if not ref:
+            assert not got or all(float(g.abs().max()) == 0.0 for g in got.values())
+            continue
+        gmax = max(float(g.abs().max()) for g in ref.values())
+        for k, g in ref.items():
+            scale = max(float(g.abs().max()), 1e-6 * gmax)
+            if scale == 0.0:                  # no active pair at this t: every gradient is exactly zero
+                assert float(got[k].abs().max()) == 0.0, (t_val, k)
+                continue
+            assert float((got[k] - g).abs().max()) / scale < 2e-4, (t_val, k)
+    net = model._denoise_fn
+    assert net.pos_emb('cuda') is net.pos_emb(b.device) is net.pos_emb(torch.device('cuda', torch.cuda.current_device()))
+    assert net.raw_params().pos_emb == net._pos_emb.data_ptr()      # 'cuda' vs 'cuda:0' once rebuilt (and freed) it per step
+    assert max(a for a, _ in seen) > min(a for a, _ in seen)
+    assert seen[3][0] > 16 and seen[3][1] > seen[3][0]         # the forced miss re-grew the capacity
