@@ -23,6 +23,9 @@ class GraphBatch:
         npg = np.asarray(nodes_per_graph, dtype=np.int64)
         B = len(npg)
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            # 'cuda' and 'cuda:0' compare unequal: keep the resolved form, the one tensors report
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.num_graphs = B
         self.num_nodes = int(npg.sum())
         node_ptr = np.zeros(B + 1, dtype=np.int64)
