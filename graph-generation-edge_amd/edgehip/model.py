@@ -139,6 +139,7 @@ class TGNN_degree_guided(nn.Module):
         self._folded = None
         self._cparams = None
         self._folded_key = None
+        self._fold_epoch = 0
 
     # ---- C structs ----------------------------------------------------------------------
     def param_slots(self):
@@ -203,13 +204,21 @@ class TGNN_degree_guided(nn.Module):
         self._raw, self._raw_key = P, key
         return P
 
+    def weights_changed(self):
+        """Tell the network its parameters were written: the next inference call refolds them.  Tensor version
+        counters catch copy_/load_state_dict/in-place ops, but torch's fused optimizers update the parameters WITHOUT
+        bumping them, so every differentiable loss (a step may follow), `edgehip.train_step` and the optimizers of
+        `edgehip.make_optimizer` (post-step hook) call this."""
+        self._fold_epoch += 1
+
     def c_params(self):
-        """(GnnParams, folded buffer); refolds when any parameter changed (version counters)."""
+        """(GnnParams, folded buffer); refolds when any parameter changed (version counters, weights_changed())."""
         dev = self.embedding_t.weight.device
         if dev.type != 'cuda':
             raise capi.EdgeHipError('the model must live on a GPU (model.to("cuda")); there is no CPU path')
         ps = list(self.parameters())
-        key = (dev, tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps), self.pos_emb(dev).data_ptr())
+        key = (dev, tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps), self.pos_emb(dev).data_ptr(),
+               self._fold_epoch)
         if key == self._folded_key:
             return self._cparams, self._folded
         for p in ps:
@@ -615,6 +624,7 @@ class BinomialDiffusionActive(nn.Module):
         if differentiable:
             from . import train
             net.pos_emb(dev)
+            net.weights_changed()           # an optimizer step may follow this loss (see weights_changed)
             counts = None
             if getattr(self, 'train_form', 'fused') != 'ops':
                 # the node part of the network needs no active pairs: it is queued before the step's only host sync

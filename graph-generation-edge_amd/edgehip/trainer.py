@@ -14,12 +14,19 @@ def make_optimizer(model, lr=1e-3, momentum=0.9, momentum_sqr=0.999):
     """The reference default: Adam(lr 1e-3, betas (0.9, 0.999)) (diffusion/optim/multistep.py:27-46).  On the GPU
     torch's fused implementation is used (same update rule, one multi-tensor launch instead of ~13)."""
     params = list(model.parameters())
+    opt = None
     if params and params[0].is_cuda:
         try:
-            return torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr), fused=True)
+            opt = torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr), fused=True)
         except (RuntimeError, TypeError):
             pass
-    return torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr))
+    if opt is None:
+        opt = torch.optim.Adam(params, lr=lr, betas=(momentum, momentum_sqr))
+    net = getattr(model, '_denoise_fn', None)
+    if net is not None and hasattr(net, 'weights_changed'):
+        # the fused update does not bump the parameters' version counters: tell the inference side to refold
+        opt.register_step_post_hook(lambda *_: net.weights_changed())
+    return opt
 
 
 def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=None, **log_prob_kwargs):
@@ -56,4 +63,7 @@ def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=N
     if clip_norm:
         torch.nn.utils.clip_grad_norm_(params, clip_norm)
     optimizer.step()
+    net = getattr(model, '_denoise_fn', None)
+    if net is not None and hasattr(net, 'weights_changed'):
+        net.weights_changed()               # whatever optimizer this was: inference refolds the weights
     return loss.detach()

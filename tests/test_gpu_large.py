@@ -226,3 +226,40 @@ def test_polblogs_scale_sub_batch_streams_repeatable():
             else:
                 assert torch.equal(first, b3.edge_index)
     assert b3.edge_index.shape[1] > 1000
+
+
+def test_polblogs_scale_training_steps_agree_with_the_inference_kernels():
+    """Reference batch of the training bench (4 polblogs-shaped graphs, T = 512), eight optimizer steps on ONE batch
+    object with a fresh t per graph every step: the loss of the fused training form (saved activations, node part queued
+    ahead of the pair count) equals, on the same (t, noise seed) and the weights of that moment, the loss of the fused
+    inference kernels (folded weights, different kernels) on a fresh batch; gradients stay finite and the weights move."""
+    import edgehip
+    from edgehip import synth
+    n, e = synth.polblogs_like(0)
+    d = synth.degrees(n, e)
+    model = H.build_model(orc.random_tgnn_params(4), 512, int(d.max()))
+    model.train()
+    B = 4
+    tb = edgehip.GraphBatch([n] * B, degree=[d] * B, edges=[e] * B, device='cuda', degree_dtype=np.int64)
+    opt = edgehip.make_optimizer(model)
+    state = {}
+    g = torch.Generator().manual_seed(3)
+    w0 = model._denoise_fn.node_in[0].weight.detach().clone()
+    for step in range(8):
+        t = torch.randint(0, 512, (B,), generator=g)
+        pt = torch.full((B,), 1.0 / 512)
+        seed = 900 + step
+        model.eval()
+        model.rng_seed = seed
+        with torch.no_grad():
+            ref = model.log_prob(edgehip.GraphBatch([n] * B, degree=[d] * B, edges=[e] * B, device='cuda',
+                                                    degree_dtype=np.int64), t, pt)
+        model.train()
+        model.rng_seed = seed
+        want = {}
+        bpd = edgehip.train_step(model, tb, opt, clip_value=1.0, state=state, t=t, pt=pt, want=want)
+        got = -(want['kl'] / want['pt'] + want['kl_prior'])
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=TOL, atol=1e-9, err_msg=f'step {step}')
+        assert np.isfinite(float(bpd))
+        assert bool(torch.isfinite(state['arena'].flat).all()) if 'arena' in state else True
+    assert float((model._denoise_fn.node_in[0].weight.detach() - w0).abs().max()) > 0

@@ -316,6 +316,13 @@ def test_train_step_matches_oracle_adam_and_learns(arena):
     with torch.no_grad():
         nv = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
     assert abs(float(-nv.sum() / (np.log(2) * P)) - losses[-1]) < 0.2 * abs(losses[0] - losses[-1]) + 1e-3
+    # ... with the weights of NOW: torch's fused Adam leaves the version counters alone, the fold cache must not
+    fresh = H.build_model(params, T, int(g['max_degree']))
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        nv3 = fresh.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
+    assert torch.allclose(nv, nv3, rtol=1e-5, atol=1e-9)
 
 
 def test_fused_and_op_forms_agree_and_two_live_forwards():
