@@ -440,3 +440,41 @@ def test_prelaunched_node_part_hit_and_miss_give_the_same_gradients():
     assert net.raw_params().pos_emb == net._pos_emb.data_ptr()      # 'cuda' vs 'cuda:0' once rebuilt (and freed) it per step
     assert max(a for a, _ in seen) > min(a for a, _ in seen)
     assert seen[3][0] > 16 and seen[3][1] > seen[3][0]         # the forced miss re-grew the capacity
+
+
+def test_importance_time_sampling_switches_on_like_the_reference():
+    """sample_time_method='importance' through train_step with no t supplied (diffusion_binomial_vanilla.py:248-269):
+    uniform t with pt = 1/T until every Lt_count exceeds 10, then t ~ multinomial(sqrt(Lt_history + 1e-10) + 1e-4 with
+    entry 0 := entry 1) with pt the probability of the drawn t.  The host-side shortcut of `_importance_ready` (no
+    device sync per step) must agree with the direct `(Lt_count > 10).all()` at every step."""
+    import edgehip
+    graphs = cases.ragged_graphs(7) + cases.ragged_graphs(9)
+    T = 48
+    model = H.build_model(orc.random_tgnn_params(5), T, cases.max_degree_of(graphs))
+    model.sample_time_method = 'importance'
+    model.rng_seed = 77
+    torch.manual_seed(5)
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    opt = edgehip.make_optimizer(model)
+    state, switched = {}, None
+    for step in range(400):
+        direct = bool((model.Lt_count > 10).all())
+        want = {}
+        edgehip.train_step(model, b, opt, clip_value=1.0, state=state, want=want)
+        pt, t = want['pt'].cpu(), want['t'].cpu()
+        if not direct:
+            assert torch.allclose(pt, torch.full_like(pt, 1.0 / T)), step
+        else:
+            if switched is None:
+                switched = step
+            assert getattr(model, '_lt_ready', False)
+            assert float(pt.min()) > 0 and not torch.allclose(pt, torch.full_like(pt, 1.0 / T)), step
+            if step - switched >= 5:
+                break
+    assert switched is not None and switched >= 11 * T // len(graphs) - 1
+    assert int(model.Lt_count.sum()) == (step + 1) * len(graphs)
+    # pt of the NEXT draw follows the formula on the buffers as they are now
+    Ls = torch.sqrt(model.Lt_history + 1e-10) + 0.0001
+    Ls[0] = Ls[1]
+    t2, pt2 = model._sample_time(len(graphs), b.device, 'importance')
+    assert torch.allclose(pt2, (Ls / Ls.sum())[t2])
