@@ -212,14 +212,16 @@ class TGNN_degree_guided(nn.Module):
         self._fold_epoch += 1
 
     def c_params(self):
-        """(GnnParams, folded buffer); refolds when any parameter changed (version counters, weights_changed())."""
+        """(GnnParams, folded buffer); refolds when any parameter changed (version counters, weights_changed()), and
+        on EVERY call once the model has been through a differentiable loss: an optimizer this package knows nothing
+        about may have stepped since (one fold launch per sampling run / evaluation batch / op-by-op reverse step)."""
         dev = self.embedding_t.weight.device
         if dev.type != 'cuda':
             raise capi.EdgeHipError('the model must live on a GPU (model.to("cuda")); there is no CPU path')
         ps = list(self.parameters())
         key = (dev, tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps), self.pos_emb(dev).data_ptr(),
                self._fold_epoch)
-        if key == self._folded_key:
+        if key == self._folded_key and self._fold_epoch == 0:
             return self._cparams, self._folded
         for p in ps:
             assert p.dtype == torch.float32 and p.is_contiguous()

@@ -478,3 +478,40 @@ def test_importance_time_sampling_switches_on_like_the_reference():
     Ls[0] = Ls[1]
     t2, pt2 = model._sample_time(len(graphs), b.device, 'importance')
     assert torch.allclose(pt2, (Ls / Ls.sum())[t2])
+
+
+def test_sampling_after_training_steps_uses_the_updated_weights():
+    """sample -> three optimizer steps -> sample on ONE model object: the second generation equals, bit for bit, the
+    generation of a fresh model that loaded the trained state_dict (same seed), and differs from the first one."""
+    import edgehip
+    graphs = cases.ragged_graphs(7) + cases.ragged_graphs(9)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(6)
+    model = H.build_model(params, T, dmax)
+    model.rng_seed = 3
+    torch.manual_seed(2)
+
+    def generate(m):
+        sb = H.graph_batch(graphs, with_edges=False, gid_base=4)
+        m.eval()
+        m.sample_batch(sb, seed=21, parts=2)
+        return sb.edge_index.clone(), sb._slice_dict['edge_index'].clone()
+
+    e0, s0 = generate(model)
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-2, fused=True)     # NOT make_optimizer: no post-step hook
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        model.train()
+        nv = model.log_prob(b)
+        (-nv.sum() / (np.log(2) * b.num_entries)).backward()
+        with torch.no_grad():                 # an evaluation between backward and step folds the OLD weights
+            model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64))
+        opt.step()
+    e1, s1 = generate(model)
+    fresh = H.build_model(params, T, dmax)
+    fresh.load_state_dict(model.state_dict())
+    e2, s2 = generate(fresh)
+    assert torch.equal(e1, e2) and torch.equal(s1, s2)
+    assert e0.shape != e1.shape or not torch.equal(e0, e1)
