@@ -112,6 +112,12 @@ class GraphBatch:
         counter-based uniforms are those of the whole batch.  Used by the sampler to run blocks of graphs on
         separate HIP streams; cached."""
         cache = self.__dict__.setdefault('_split_cache', {})
+        # the blocks alias self.adj and copy d0: a caller that rebinds either gets fresh blocks
+        stamp = (self.adj.data_ptr(), None if self.degree_i32 is None else
+                 (self.degree_i32.data_ptr(), self.degree_i32._version))
+        if cache.get('stamp') != stamp:
+            cache.clear()
+            cache['stamp'] = stamp
         if parts in cache:
             return cache[parts]
         B = self.num_graphs

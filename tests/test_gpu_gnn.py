@@ -220,6 +220,14 @@ def test_sampler_on_sub_batch_streams_is_bit_identical(parts):
     model.sample_batch(b1, seed + 1, parts=1)
     assert torch.equal(b1.edge_index, bk.edge_index)
     assert model.default_parts(64) == 3 and model.default_parts(7) == 1 and model.default_parts(16) == 2
+    # new target degrees written into the same batch object: the cached blocks (which copy d0) are rebuilt
+    halved = torch.div(bk.degree_i32, 2, rounding_mode='floor')
+    for b in (b1, bk):
+        b.degree_i32.copy_(halved)
+        b.degree.copy_(halved.to(b.degree.dtype))
+    model.sample_batch(bk, seed + 2, parts=parts)
+    model.sample_batch(b1, seed + 2, parts=1)
+    assert torch.equal(b1.edge_index, bk.edge_index)
 
 
 def test_sample_api_polblogs_shape():
