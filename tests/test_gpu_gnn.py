@@ -286,3 +286,24 @@ def test_live_row_compaction_matches_full_computation(state):
     rows = np.concatenate([np.arange(kp[g], kp[g + 1]) for g in range(b.num_graphs) if kp[g + 1] - kp[g] >= 2])
     assert len(rows) > 4
     assert H.rel_err(outs[0][rows], outs[1][rows]) < 2e-6
+
+
+def test_one_model_samples_batches_of_growing_and_shrinking_max_degree():
+    """The posterior table is sized by the largest target degree seen so far and rebuilt when a batch exceeds it:
+    a model that sampled a low-degree batch, then a high-degree one, then the first again gives on each what a fresh
+    model gives (bit for bit), whatever table it holds at that moment."""
+    low = cases.ragged_graphs(3)
+    high = cases.ragged_graphs(9) + cases.ragged_graphs(4)
+    T = 40
+    dmax = max(cases.max_degree_of(low), cases.max_degree_of(high))
+    assert cases.max_degree_of(low) != cases.max_degree_of(high)
+    params = orc.random_tgnn_params(8)
+    model = H.build_model(params, T, dmax)
+    for k, graphs in enumerate((low, high, low, high) if cases.max_degree_of(low) < cases.max_degree_of(high)
+                               else (high, low, high, low)):
+        b = H.graph_batch(graphs, with_edges=False, gid_base=2)
+        model.sample_batch(b, 50 + k, parts=2)
+        fb = H.graph_batch(graphs, with_edges=False, gid_base=2)
+        H.build_model(params, T, dmax).sample_batch(fb, 50 + k, parts=1)
+        assert torch.equal(b.edge_index, fb.edge_index), k
+        assert torch.equal(b._slice_dict['edge_index'], fb._slice_dict['edge_index']), k
