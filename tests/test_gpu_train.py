@@ -515,3 +515,45 @@ def test_sampling_after_training_steps_uses_the_updated_weights():
     e2, s2 = generate(fresh)
     assert torch.equal(e1, e2) and torch.equal(s1, s2)
     assert e0.shape != e1.shape or not torch.equal(e0, e1)
+
+
+def test_alternating_batches_share_one_model_and_arena():
+    """Two batch objects of different size stepped alternately through one model and one gradient arena (each batch
+    keeps its own workspace / capacity / queued node part): loss and arena gradients of every step equal those of a
+    fresh model and batch."""
+    from edgehip import train
+    sets = [cases.ragged_graphs(7), cases.ragged_graphs(9) + cases.ragged_graphs(4)]
+    T = 48
+    dmax = max(cases.max_degree_of(g) for g in sets)
+    params = orc.random_tgnn_params(17)
+    model = H.build_model(params, T, dmax)
+    model.train()
+    arena = train.GradArena(list(model.parameters()))
+    batches = [H.graph_batch(g, degree_dtype=np.int64) for g in sets]
+    for step, (which, t_val) in enumerate([(0, 5), (1, 12), (0, 20), (1, 3), (1, 30), (0, 2)]):
+        graphs, b = sets[which], batches[which]
+        t = torch.full((len(graphs),), t_val)
+        pt = torch.full((len(graphs),), 1.0 / T)
+        model.rng_seed = 40 + step
+        arena.zero_and_attach()
+        b._train_ws_busy = False
+        with train.use_arena(arena):
+            nv = model.log_prob(b, t, pt)
+            (-nv.sum() / (np.log(2) * b.num_entries)).backward()
+        fresh = H.build_model(params, T, dmax)
+        fresh.train()
+        fresh.rng_seed = 40 + step
+        fb = H.graph_batch(graphs, degree_dtype=np.int64)
+        nv2 = fresh.log_prob(fb, t, pt)
+        (-nv2.sum() / (np.log(2) * fb.num_entries)).backward()
+        assert torch.allclose(nv.detach(), nv2.detach(), rtol=1e-5, atol=1e-9), step
+        ref = dict(fresh._denoise_fn.named_parameters())
+        gmax = max(float(v.grad.abs().max()) for v in ref.values() if v.grad is not None)
+        assert gmax > 0
+        for k, v in model._denoise_fn.named_parameters():
+            g = ref[k].grad
+            if g is None:
+                assert float(v.grad.abs().max()) == 0.0, (step, k)
+                continue
+            scale = max(float(g.abs().max()), 1e-6 * gmax)
+            assert float((v.grad - g).abs().max()) / scale < 2e-4, (step, k)
