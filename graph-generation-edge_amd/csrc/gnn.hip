@@ -888,6 +888,7 @@ struct eh_layer_args {
     const int32_t* idle;                               // kptr: tiles of graphs without active pairs exit (or null)
     const int32_t* crow; const float* cwgt; const int32_t* ccount;   // live rows (k_compact): node ids, weights, count per graph
     float* hnew; float* part;
+    int count_rows;                                    // edgehip_prof_enable(1): add the processed rows to eh_layer_rows
 };
 
 #ifdef EH_STAMP
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     const int cbase = L.node_ptr[g] + 32 * (tile - L.tile_ptr[g]);
     const int rows = min(32, L.node_ptr[g] + a.ccount[g] - cbase);
     if (rows <= 0) return;
-    if (tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // executed work, for the roofline figure
+    if (a.count_rows && tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // measurement runs only (roofline figure)
     const int r = lane & 31, hh = lane >> 5;
     const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
@@ -1543,6 +1544,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
         la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
         la.crow = w.crow; la.cwgt = w.cwgt; la.ccount = w.ccount;
+        la.count_rows = eh_prof_on() ? 1 : 0;
         // per-graph update of this layer and qt of the heavy rows (gathered-row GEMM into the compact buffer
         // w.Qt) in ONE launch: they are independent, and each alone is a latency-bound launch
         {
@@ -1715,7 +1717,9 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
                 uint32_t* g = a.adj + L.adj_ptr[b];
                 uint32_t* ri = g + (int64_t)gi * stride;
                 uint32_t* rj = g + (int64_t)gj * stride;
-                if (MODE == 0) {
+                if (MODE == 0 && a.adj == nullptr) {
+                    // logits-only call (edgehip_edge_resample with adj == NULL): nothing is drawn, nothing written
+                } else if (MODE == 0) {
                     float u0, u1;
                     if (a.use_rng) {
                         int64_t n = L.node_ptr[b + 1] - node0;
@@ -1764,8 +1768,9 @@ extern "C" int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_
                                      const float* logits_in, int32_t logits_are_logprobs, const float* uniforms,
                                      const edgehip_rng* rng, int32_t step, const float* gumbel_lut, uint32_t* adj,
                                      float* logits_out, uint8_t* bits_out, int64_t pair_cap, void* stream) {
-    EH_CHECK_ARG(L && act_nodes && kptr && aptr && tptr && counts && adj);
-    EH_CHECK_ARG(uniforms || rng);
+    EH_CHECK_ARG(L && act_nodes && kptr && aptr && tptr && counts);
+    EH_CHECK_ARG(adj || logits_out);              // adj == NULL: logits only (no draw, the state is not touched)
+    EH_CHECK_ARG(!adj || uniforms || rng);
     EH_CHECK_ARG(logits_in || (node_repr && P && folded));
     if (!logits_in) { int rc = eh_check_params(P); if (rc != EDGEHIP_OK) return rc; }
     if (L->num_graphs == 0) return EDGEHIP_OK;

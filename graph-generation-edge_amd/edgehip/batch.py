@@ -91,14 +91,24 @@ class GraphBatch:
             self.set_edges(self.adj, ge)
             if degree is None:
                 deg = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
-                capi.check(capi.lib.edgehip_degree_from_adj(C_byref(L), self.adj.data_ptr(), deg.data_ptr(),
-                                                            capi.stream_ptr()), 'degree_from_adj')
+                with self._dev():
+                    capi.check(capi.lib.edgehip_degree_from_adj(C_byref(L), self.adj.data_ptr(), deg.data_ptr(),
+                                                                capi.stream_ptr()), 'degree_from_adj')
                 self.degree_i32 = deg
                 self.degree = deg.long()
         self._slice_dict, self._inc_dict = {}, {}
 
     # ---- helpers -------------------------------------------------------------------------
+    def _dev(self):
+        """Context with this batch's GPU current (the library launches on the current device's current stream)."""
+        import contextlib
+        return torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()
+
     def set_edges(self, adj, global_edges):
+        with self._dev():
+            return self._set_edges(adj, global_edges)
+
+    def _set_edges(self, adj, global_edges):
         ge = torch.from_numpy(np.ascontiguousarray(global_edges, dtype=np.int32)).to(self.device)
         capi.check(capi.lib.edgehip_adj_from_edges(C_byref(self.layout), capi.ptr(ge) if ge.numel() else None,
                                                    ge.shape[0], adj.data_ptr(), capi.stream_ptr()), 'adj_from_edges')
@@ -146,7 +156,10 @@ class GraphBatch:
 
     def extract_edges(self, adj=None):
         """edge_index [2,E] int64 (i<j, ascending pair order) and edge_slice [B+1] of a state."""
-        adj = self.adj if adj is None else adj
+        with self._dev():
+            return self._extract_edges(self.adj if adj is None else adj)
+
+    def _extract_edges(self, adj):
         row_upper = torch.empty(max(self.num_nodes, 1), dtype=torch.int32, device=self.device)
         edge_slice = torch.zeros(self.num_graphs + 1, dtype=torch.int64, device=self.device)
         s = capi.stream_ptr()

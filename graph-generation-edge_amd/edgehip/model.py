@@ -21,6 +21,22 @@ from .batch import GraphBatch
 byref = C.byref
 
 
+def _on_batch_device(fn):
+    """Run an entry point with the batch's GPU current: the library launches on `torch.cuda.current_stream()` and keeps
+    per-device state by hipGetDevice, so a batch on cuda:1 called while cuda:0 is current would put kernels on device
+    0's stream against device 1's pointers.  The batch is the first positional argument after self."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, batch, *a, **k):
+        dev = getattr(batch, 'device', None)
+        if dev is not None and torch.device(dev).type == 'cuda':
+            with torch.cuda.device(dev):
+                return fn(self, batch, *a, **k)
+        return fn(self, batch, *a, **k)
+    return wrapped
+
+
 def add_model_args(parser):
     """Same flags and defaults as the reference (model.py:11-24)."""
     parser.add_argument('--loss_type', type=str, default='vb_kl')
@@ -112,6 +128,8 @@ class TGNN_degree_guided(nn.Module):
             raise NotImplementedError("only --norm None (the reference default) is implemented")
         if len(num_heads) > capi.MAX_LAYERS or any(h not in (1, 2, 4, 8) for h in num_heads):
             raise NotImplementedError('num_heads entries must be in {1,2,4,8}, at most 8 layers')
+        if num_edge_classes != 2:
+            raise NotImplementedError('the kernels implement the binomial (2 edge classes) diffusion only')
         if not kwargs.get('gru', False):
             raise NotImplementedError('the reference factory always builds the GRU variant (model.py:56)')
         self.max_degree, self.num_classes, self.num_heads = max_degree, num_edge_classes, list(num_heads)
@@ -240,6 +258,7 @@ class TGNN_degree_guided(nn.Module):
         self._cparams, self._folded_key = P, key
         return P, self._folded
 
+    @_on_batch_device
     def forward(self, pyg_data, t_node, t_edge=None):
         """(log_node_attr passthrough, edge_logits [A,2]) - layers/layers.py:315,383.
 
@@ -263,14 +282,12 @@ class TGNN_degree_guided(nn.Module):
         A = int(st['aptr'][-1].item())
         logits = torch.empty((A, 2), dtype=torch.float32, device=pyg_data.device)
         if A:
-            # logits only: run the pair tail with a throw-away copy of the state
-            scratch = st['adj_t'].clone()
-            u = torch.zeros((A, 2), dtype=torch.float32, device=pyg_data.device)
+            # logits only (adj = NULL): the pair tail without a draw, the state is not touched
             capi.check(capi.lib.edgehip_edge_resample(byref(L), byref(P), folded.data_ptr(), node_repr.data_ptr(),
                                                       st['act_nodes'].data_ptr(), st['kptr'].data_ptr(),
                                                       st['aptr'].data_ptr(), st['tptr'].data_ptr(),
-                                                      st['counts'].data_ptr(), None, 0, u.data_ptr(), None, 0, None,
-                                                      scratch.data_ptr(), logits.data_ptr(), None, A, s),
+                                                      st['counts'].data_ptr(), None, 0, None, None, 0, None,
+                                                      None, logits.data_ptr(), None, A, s),
                        'edge_resample(logits)')
         return getattr(pyg_data, 'log_node_attr', None), logits
 
@@ -343,6 +360,7 @@ class BinomialDiffusionActive(nn.Module):
         return int(torch.randint(0, 2 ** 62, (1,)).item())
 
     # ---- a10 / a16 : reverse step ---------------------------------------------------------
+    @_on_batch_device
     def _p_sample_and_set_actives(self, batch, t, u_node=None, rng=None):
         """diffusion_binomial_active.py:121-128. t: python int (shared) or int32 tensor [B]."""
         L, dev = batch.layout, batch.device
@@ -389,6 +407,7 @@ class BinomialDiffusionActive(nn.Module):
             c = pinned.numpy().copy().view(np.int32)
         return int(c[0]), int(c[2:4].view(np.int64)[0])
 
+    @_on_batch_device
     def materialize_actives(self, batch, counts=None):
         """Sets batch.active_node_indices / active_edge_indices (int64, ascending) like the reference."""
         st, L = batch._state, batch.layout
@@ -405,6 +424,7 @@ class BinomialDiffusionActive(nn.Module):
         batch.active_row, batch.active_col = row, col
         return ani, aei
 
+    @_on_batch_device
     @torch.no_grad()
     def p_sample(self, batch, t, u_node=None, u_pair=None, rng=None, logits_in=None, want=None):
         """One reverse step, op by op (diffusion_binomial_active.py:72-90).  With supplied uniforms
@@ -455,6 +475,7 @@ class BinomialDiffusionActive(nn.Module):
         111.8 graphs/s; a process has 4 hardware queues, a fifth stream shares one: 82.6)."""
         return max(1, min(3, num_graphs // 8))
 
+    @_on_batch_device
     @torch.no_grad()
     def sample_batch(self, batch, seed=None, parts=None):
         """T fused reverse steps of a prepared batch (no host sync), then the edge-list epilogue.
@@ -536,9 +557,27 @@ class BinomialDiffusionActive(nn.Module):
         self._lt_ready = ready
         return ready
 
+    _SCHEDULE_KEYS = ('log_alpha', 'log_1_min_alpha', 'log_cumprod_alpha', 'log_1_min_cumprod_alpha',
+                      'log_final_prob_node', 'log_final_prob_edge')
+
     def load_state_dict(self, *args, **kwargs):
         self._lt_ready, self._lt_samples = False, None      # Lt_count may change under us
-        return super().load_state_dict(*args, **kwargs)
+        out = super().load_state_dict(*args, **kwargs)
+        self._refresh_schedule()
+        return out
+
+    def _refresh_schedule(self):
+        """The kernels read host-built tables (posterior, q tables, prior-KL constants), not the registered buffers.
+        The reference always computes from the buffers a checkpoint restored (diffusion/base.py:171), so after a load
+        the tables are rebuilt from them - whatever --noise_schedule the constructor was given, and whether the
+        module was moved to the GPU before or after the load."""
+        buf = {k: getattr(self, k).detach().cpu().clone() for k in self._SCHEDULE_KEYS}
+        if all(torch.equal(buf[k], self._host_buf[k]) for k in self._SCHEDULE_KEYS):
+            return
+        self._host_buf = buf
+        self._q_cum_h, self._q_one_h = tables.q_tables(buf)
+        self._tabs = {}
+        self._kl_consts = None
 
     def _sample_time(self, b, device, method='uniform'):
         """diffusion_binomial_vanilla.py:248-269."""
@@ -561,7 +600,7 @@ class BinomialDiffusionActive(nn.Module):
         """diffusion_binomial_vanilla.py:116-136.  Every element of a class contributes the same
         value, so the per-graph sum is count x value (three values, computed with the reference's ops)."""
         cached = getattr(batch, '_kl_prior_cache', None)
-        if cached is not None and cached[0] is self:
+        if cached is not None and cached[0] is self._host_buf:
             return cached[1]
         consts = getattr(self, '_kl_consts', None)
         if consts is None:
@@ -581,7 +620,7 @@ class BinomialDiffusionActive(nn.Module):
         P = batch.edges_per_graph.double()
         E = _x0_edge_counts(batch).double()
         out = (n * kn + (P - E) * k0 + E * k1).float()
-        batch._kl_prior_cache = (self, out)        # x0, the sizes and the schedule are fixed for a batch object
+        batch._kl_prior_cache = (self._host_buf, out)        # x0, the sizes and the schedule are fixed for a batch object
         return out
 
     # ---- a18, a21 : loss -------------------------------------------------------------------------
@@ -595,6 +634,7 @@ class BinomialDiffusionActive(nn.Module):
         with torch.no_grad():
             return self._loss(batch, self.training, t, pt, u_tm1, u_t, want)
 
+    @_on_batch_device
     def _loss(self, batch, training, t, pt, u_tm1, u_t, want, differentiable=False):
         """_train_loss / _eval_loss, diffusion_binomial_active.py:228-264 / 195-226. Returns -vb [B].
         differentiable=False: the fused inference kernels (no grad).  True: the op-by-op training form
@@ -606,6 +646,10 @@ class BinomialDiffusionActive(nn.Module):
         nmax = 0
         tabs = self._tables(dev, nmax)
         st = _state(batch)
+        if differentiable:
+            # the autograd node keeps deg_t / flags for its backward: a second differentiable loss on the same batch
+            # before the first backward must not overwrite them (adj_t, adj_tm1, deg_tm1 are fresh per call already)
+            st['deg_t'], st['flags'] = torch.zeros_like(st['deg_t']), torch.zeros_like(st['flags'])
         s = capi.stream_ptr()
         t_graph = t.to(torch.int32).contiguous()
         adj_tm1, adj_t = batch.new_adj(), batch.new_adj()

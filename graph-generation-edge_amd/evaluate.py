@@ -59,6 +59,8 @@ def main(argv=None):
             for k, v in json.load(fh).items():
                 setattr(a, k, v)
     torch.manual_seed(a.seed)
+    if torch.device(a.device).type == 'cuda':
+        torch.cuda.set_device(torch.device(a.device))     # the library launches on the CURRENT device's stream
     if a.synthetic:
         graphs = [getattr(synth, a.synthetic)(0)]
     elif a.edge_list:

@@ -13,6 +13,16 @@
  *     kernels read them from `edgehip_counts` and launch over fixed upper bounds, so the
  *     sampling loop needs no host synchronisation.
  *
+ * Process state: the data path keeps none.  Two documented exceptions, both per device and created on
+ * first use: (1) edgehip_train_backward* queue the weight-gradient products on a library-owned
+ * non-blocking side stream joined back into `stream` before the call returns its work (csrc/train.hip
+ * tr_aux; it never outlives an entry point's ordering: the caller sees one stream); (2) the measurement hooks at
+ * the end of this file (off by default).  edgehip_edge_ce_loss_static additionally owns a fixed device
+ * scratch array (see there).
+ *
+ * SURVEY.md 8b lists an op 6 `csr_build`: it is intentionally ABSENT.  The bit-matrix state below IS the
+ * adjacency structure (a row is a sorted neighbour list), so no CSR is ever built.
+ *
  * State layout (replaces the reference's dense log-one-hot `[P,2]` state and its
  * int64 `full_edge_index [2,P]`, datasets/data_utils.py:53-56): one symmetric BIT MATRIX
  * per graph.  Graph b owns `n_b` rows of `adj_stride[b]` 32-bit words starting at word
@@ -204,7 +214,9 @@ int edgehip_gnn_forward(const edgehip_layout* L, const edgehip_gnn_params* P, co
  * uniforms: [A,2] in active-pair order, or NULL for rng (stream 1, keyed by the pair's index in
  * the P enumeration).  Optional outputs (NULL to skip): logits_out [A,2], bits_out [A] (cap pair_cap).
  * logits_in: NULL, or [A,2] externally supplied logits that replace the network's (parity tests:
- * "sampled edges bit-exact given logits + uniforms"). `logits_are_logprobs` != 0 skips log_softmax. */
+ * "sampled edges bit-exact given logits + uniforms"). `logits_are_logprobs` != 0 skips log_softmax.
+ * adj == NULL: logits-only call (the denoiser contract `denoise_fn(batch, t_node, t_edge) -> edge_logits`,
+ * active:148): logits_out is filled, nothing is drawn and no state is touched (uniforms/rng may be NULL). */
 int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
                           const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
                           const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,

@@ -52,3 +52,45 @@ def test_evaluate_script_loads_checkpoint_and_samples(tmp_path):
     torch.save({'model': bad}, tmp_path / 'bad.pt')
     with pytest.raises(RuntimeError):
         ev.main(['--checkpoint_path', str(tmp_path / 'bad.pt'), '--edge_list', *files, '--diffusion_steps', str(T)])
+
+
+@pytest.mark.parametrize('order', ['load_then_cuda', 'cuda_then_load'])
+def test_loaded_schedule_buffers_drive_the_kernels(order):
+    """A checkpoint carries its schedule buffers (log_alpha ... ; diffusion/base.py:158,171).  The reference always
+    computes from them, whatever --noise_schedule says at load time; the kernel tables here are host-built, so they
+    must be rebuilt on load - in either order of .to(device) and load_state_dict."""
+    import edgehip
+    graphs = [g for g in cases.ragged_graphs(6) if len(g['edges']) > 3]
+    T, dmax = 32, cases.max_degree_of(graphs)
+    sampler = lambda: edgehip.EmpiricalEmptyGraphGenerator([(g['n'], g['edges']) for g in graphs], degree=True, device='cuda')
+
+    def build(schedule, device):
+        a = H.make_args(T, dmax, device)
+        a.noise_schedule = schedule
+        m = edgehip.get_model(a, sampler())
+        m._denoise_fn.load_state_dict(orc.random_tgnn_params(21), strict=True)
+        return m
+    src = build('cosine', 'cuda').to('cuda').eval()
+    sd = {k: v.cpu() for k, v in src.state_dict().items()}
+    dst = build('linear', 'cuda')
+    assert not torch.equal(dst.log_alpha.cpu(), sd['log_alpha'])
+    if order == 'load_then_cuda':
+        dst.load_state_dict(sd)
+        dst = dst.to('cuda').eval()
+    else:
+        dst = dst.to('cuda').eval()
+        dst.load_state_dict(sd)
+    import random
+    torch.manual_seed(5); random.seed(5)
+    a = src.sample(6, seed=11)
+    torch.manual_seed(5); random.seed(5)
+    b = dst.sample(6, seed=11)
+    assert a.edge_index.shape[1] > 0 and torch.equal(a.edge_index, b.edge_index)
+    # and the loss path (q tables, prior-KL constants) follows too
+    gb = lambda: H.graph_batch(graphs, degree_dtype=np.int64)
+    t = torch.tensor([3, 9, 20, 30][:len(graphs)] + [1] * max(0, len(graphs) - 4))
+    pt = torch.full((len(graphs),), 1.0 / T)
+    src.rng_seed = dst.rng_seed = 77
+    with torch.no_grad():
+        la, lb = src.log_prob(gb(), t, pt), dst.log_prob(gb(), t, pt)
+    assert torch.equal(la, lb)

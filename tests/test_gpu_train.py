@@ -366,6 +366,49 @@ def test_fused_and_op_forms_agree_and_two_live_forwards():
             assert err < 2e-4, (k, other, err)
 
 
+def test_second_live_forward_with_other_t_does_not_corrupt_the_first_backward():
+    """Two differentiable losses alive on ONE batch object, the second with different t and uniforms: the first
+    backward must still see its own degrees / active flags (they feed the embedding gradients).  Reference = the
+    same first loss evaluated alone on a fresh batch."""
+    graphs = cases.ragged_graphs(7) + cases.ragged_graphs(8)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(11)
+    rng = np.random.default_rng(6)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    ua = [cases.uniforms(rng, P, 2).cuda() for _ in range(2)]
+    ub = [cases.uniforms(rng, P, 2).cuda() for _ in range(2)]
+    ta = torch.tensor([5, 9, 3, 20, 1, 13] * 2)
+    tb = torch.tensor([30, 2, 17, 4, 40, 25] * 2)
+    pt = torch.full((len(graphs),), 1.0 / T)
+
+    def grads_of(model):
+        return {k: v.grad.detach().clone() for k, v in model._denoise_fn.named_parameters() if v.grad is not None}
+    for form in ('fused', 'ops'):
+        alone = H.build_model(params, T, dmax)
+        alone.train()
+        alone.train_form = form
+        b0 = H.graph_batch(graphs, degree_dtype=np.int64)
+        nv0 = alone.log_prob(b0, ta, pt, ua[0], ua[1])
+        (-nv0.sum() / (np.log(2) * b0.num_entries)).backward()
+        ref = grads_of(alone)
+        model = H.build_model(params, T, dmax)
+        model.train()
+        model.train_form = form
+        b = H.graph_batch(graphs, degree_dtype=np.int64)
+        nv1 = model.log_prob(b, ta, pt, ua[0], ua[1])
+        nv2 = model.log_prob(b, tb, pt, ub[0], ub[1])          # overwrote deg_t / flags of the first before the fix
+        assert not torch.allclose(nv1, nv2)
+        (-nv1.sum() / (np.log(2) * b.num_entries)).backward()
+        got = grads_of(model)
+        gmax = max(float(g.abs().max()) for g in ref.values())
+        for k in ('embedding_t.weight', 'embedding_0.weight', 'embedding_sel.weight', 'node_in.0.weight'):
+            scale = max(float(ref[k].abs().max()), 1e-6 * gmax)
+            err = float((got[k] - ref[k]).abs().max()) / scale
+            assert err < 2e-4, (form, k, err)
+        del nv2
+
+
 def test_train_entry_points_reject_bad_arguments():
     from edgehip import capi
     graphs = cases.ragged_graphs(3)
