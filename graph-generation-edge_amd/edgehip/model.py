@@ -337,7 +337,7 @@ class BinomialDiffusionActive(nn.Module):
             self.register_buffer(k, v)
         self.register_buffer('Lt_history', torch.zeros(timesteps))
         self.register_buffer('Lt_count', torch.zeros(timesteps))
-        self._host_buf = buf
+        self._host_buf = {k: v.clone() for k, v in buf.items()}     # NOT the registered tensors: a load copies into those in place
         self._q_cum_h, self._q_one_h = tables.q_tables(buf)       # also validates the sparse formulation
         self._tabs = {}
         self.rng_seed = None
