@@ -1824,6 +1824,51 @@ extern "C" int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_p
 }
 
 // --------------------------------------------------------------------------------------------
+// The same loss for callers that cannot allocate (HIP graph capture, tight serving loops): the per-tile
+// partial sums live in a file-scope device array instead of a caller buffer.  Every GPU holds its own copy
+// of the array at its own address; host code must use the address hipGetSymbolAddress returns for the
+// CURRENT device, never the array's name (that is a host-side stand-in, not a device pointer).
+// --------------------------------------------------------------------------------------------
+#define EH_CE_STATIC_TILES (1 << 21)            // 2 Mi pair tiles = 8 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[EH_CE_STATIC_TILES];
+#include <mutex>
+static float* g_scratch_ptr[64];                // per device, resolved once with that device current
+static std::mutex g_scratch_mu;
+
+static int eh_scratch_for_current_device(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return EDGEHIP_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return EDGEHIP_ERR_LAUNCH;
+        g_scratch_ptr[dev] = reinterpret_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return EDGEHIP_OK;
+}
+
+extern "C" int64_t edgehip_edge_ce_loss_static_max_tiles(void) { return EH_CE_STATIC_TILES; }
+
+extern "C" int edgehip_edge_ce_loss_static(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                                           const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
+                                           const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
+                                           const uint32_t* adj_tm1, float* kl, float* logits_out, int64_t pair_cap,
+                                           void* stream) {
+    EH_CHECK_ARG(L);
+    // upper bound of the pair tiles any active set of this layout can have: every graph all-active
+    const int64_t n = L->max_nodes;
+    const int64_t bound = (int64_t)L->num_graphs * ((n * (n - 1) / 2 + EDGEHIP_PAIR_TILE - 1) / EDGEHIP_PAIR_TILE + 1);
+    if (bound > EH_CE_STATIC_TILES) return EDGEHIP_ERR_TOO_LARGE;
+    float* sp = nullptr;
+    int rc = eh_scratch_for_current_device(&sp);
+    if (rc != EDGEHIP_OK) return rc;
+    // every tile the reduction reads is written by this call's pair kernel first: nothing has to start at zero
+    return edgehip_edge_ce_loss(L, P, folded, node_repr, act_nodes, kptr, aptr, tptr, counts, adj_tm1, sp,
+                                EH_CE_STATIC_TILES, kl, logits_out, pair_cap, stream);
+}
+
+// --------------------------------------------------------------------------------------------
 // one reverse step (p_sample) for the whole batch, no host sync
 // --------------------------------------------------------------------------------------------
 __global__ void k_fill_i32(int32_t* p, int n, int v) {

@@ -15,9 +15,9 @@ NSTAT = 10
 TILE_ROWS = 32
 PAIR_TILE = 32
 
-OK, ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 _ERR = {ERR_ARG: 'bad argument', ERR_UNSUPPORTED: 'unsupported configuration', ERR_WORKSPACE: 'workspace too small',
-        ERR_LAUNCH: 'kernel launch failed'}
+        ERR_LAUNCH: 'kernel launch failed', ERR_TOO_LARGE: 'input exceeds the fixed capacity of a no-allocation entry point'}
 STATUS_CAPACITY = 1
 
 vp = C.c_void_p
@@ -73,6 +73,8 @@ EXPORTS = {
                               C.POINTER(Rng), C.c_int32, vp, vp, vp, vp, C.c_int64, vp],
     'edgehip_edge_ce_loss': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64,
                              vp, vp, C.c_int64, vp],
+    'edgehip_edge_ce_loss_static': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    C.c_int64, vp],
     'edgehip_sample_step': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp,
                             C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
     'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],
@@ -130,6 +132,7 @@ def _load():
         f.argtypes = args
         f.restype = C.c_size_t
     lib.edgehip_version.restype = C.c_char_p
+    lib.edgehip_edge_ce_loss_static_max_tiles.restype = C.c_int64
     lib.edgehip_prof_enable.argtypes = [C.c_int]
     lib.edgehip_prof_enable.restype = C.c_int
     lib.edgehip_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
@@ -154,6 +157,7 @@ def check(rc, what=''):
         raise EdgeHipError(f'{what}: {_ERR.get(rc, rc)} ({rc})')
 
 
+MISC_EXPORTS = ('edgehip_edge_ce_loss_static_max_tiles',)
 PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels',
                 'edgehip_prof_layer_rows')
 

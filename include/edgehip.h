@@ -44,6 +44,7 @@ extern "C" {
 #define EDGEHIP_ERR_UNSUPPORTED (-2)  /* configuration outside what the kernels implement */
 #define EDGEHIP_ERR_WORKSPACE (-3)    /* workspace too small */
 #define EDGEHIP_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch */
+#define EDGEHIP_ERR_TOO_LARGE (-5)    /* input beyond the fixed capacity of an entry point that cannot allocate */
 
 #define EDGEHIP_MAX_LAYERS 8
 #define EDGEHIP_TILE_ROWS 32          /* node tile: 32 consecutive nodes of ONE graph */
@@ -233,6 +234,22 @@ int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_params* P, c
                          const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
                          const uint32_t* adj_tm1, float* tile_partial, int64_t tile_cap, float* kl,
                          float* logits_out, int64_t pair_cap, void* stream);
+
+/* ---- the same loss without any caller scratch -------------------------------------------------
+ * NO COUNTERPART in the reference.  For callers that cannot allocate device memory or size a workspace:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Identical to
+ * edgehip_edge_ce_loss (same kernels, same results bit for bit) except that the per-tile partial sums live in
+ * a fixed device array owned by the library: edgehip_edge_ce_loss_static_max_tiles() floats (2 Mi = 8 MiB) per
+ * GPU the library runs on, held until the process ends.  The call allocates and frees nothing.
+ * Limit: num_graphs * (ceil(max_nodes*(max_nodes-1)/2 / 32) + 1) must not exceed the maximum (64 polblogs
+ * graphs fit), else EDGEHIP_ERR_TOO_LARGE and nothing is launched.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams) race. */
+int64_t edgehip_edge_ce_loss_static_max_tiles(void);
+int edgehip_edge_ce_loss_static(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
+                                const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
+                                const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
+                                const uint32_t* adj_tm1, float* kl, float* logits_out, int64_t pair_cap,
+                                void* stream);
 
 /* ---- a16+a10+a12 fused: one reverse step for the whole batch --------------------------------
  * replaces: BinomialDiffusionActive.p_sample, diffusion/diffusion_binomial_active.py:72-90

@@ -81,7 +81,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/edgehip.h but not exported'
-    assert set(capi.EXPORTS) | set(capi.SIZE_EXPORTS) | set(capi.PROF_EXPORTS) | {'edgehip_version'} == names
+    assert set(capi.EXPORTS) | set(capi.SIZE_EXPORTS) | set(capi.PROF_EXPORTS) | set(capi.MISC_EXPORTS) | {'edgehip_version'} == names
     assert b'gfx950' in capi.lib.edgehip_version()
 
 
