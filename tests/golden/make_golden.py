@@ -358,6 +358,92 @@ def gen_traj(case):
     print(f'    final edges per graph: {np.diff(res._slice_dict["edge_index"].numpy()).tolist()}')
 
 
+def gen_traj_big(case='polblogs1'):
+    """Whole T-step reference trajectory of ONE polblogs-scale graph (~10^6 Gumbel decisions on network logits),
+    stored compactly: per step the active-node list, the pairs whose bit changed, the smallest decision margin
+    with the reference logits of that pair, and full logits at a few steps.  Uniforms are NOT stored: the tests
+    redraw them from the same seeded generator in the same consumption order."""
+    print(f'polblogs-scale trajectory: {case}')
+    builder, T, wseed, useed = cases.CASES[case]
+    graphs = builder()
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(wseed)
+    model = build_ref_model(params, T, dmax)
+    rng = np.random.default_rng(useed + 3)
+    empty = [dict(n=g['n'], edges=None, degree=synth_deg(g)) for g in graphs]
+    rb = ref_batch(empty)
+    last = {}
+
+    def draw(x, *a, **k):
+        u = cases.uniforms(rng, *x.shape)
+        last['u'] = u
+        return u.clone()
+    torch.rand_like = draw
+
+    class Sampler:
+        def sample(self, n):
+            return rb
+    model.initial_graph_sampler = Sampler()
+    seen = {}
+    model._denoise_fn.register_forward_hook(lambda mod, inp, out: seen.__setitem__('logits', out[1].detach().clone()))
+    LOGIT_STEPS = (450, 350, 250, 150, 100, 50, 5)
+    rec = dict(K=[], K_off=[0], delta=[], delta_off=[0], A=[], E=[], min_margin=[], min_margin_k=[], min_margin_logits=[])
+    prev = np.zeros(0, np.int64)
+    extra = {}
+    import time
+    t0 = time.time()
+
+    def spy(batched_graph, t_node, t_edge):
+        nonlocal prev
+        seen.pop('logits', None)
+        out = BinomialDiffusionActive.p_sample(model, batched_graph, t_node, t_edge)
+        t = int(t_node[0])
+        K = batched_graph.active_node_indices.numpy().astype(np.int32)
+        A = int(batched_graph.active_edge_indices.shape[0])
+        state = ones_idx(out[1])
+        rec['K'].append(K); rec['K_off'].append(rec['K_off'][-1] + len(K))
+        d = np.setxor1d(prev, state).astype(np.int64)
+        rec['delta'].append(d); rec['delta_off'].append(rec['delta_off'][-1] + len(d))
+        rec['A'].append(A); rec['E'].append(len(state))
+        mm, mk, ml = np.float32(np.inf), -1, np.zeros(2, np.float32)
+        if A:
+            lg = seen['logits']
+            lp = torch.log_softmax(lg, dim=1)
+            u = last['u']
+            assert tuple(u.shape) == (A, 2)
+            gum = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+            s = gum + lp
+            margin = (s[:, 1] - s[:, 0])
+            # the reference's own draw, recomputed: must reproduce the bits it wrote
+            bits = out[1][batched_graph.active_edge_indices].argmax(1)
+            assert torch.equal((margin > 0).long(), bits)
+            k = int(margin.abs().argmin())
+            mm, mk, ml = np.float32(margin[k]), k, lg[k].numpy()
+            if t in LOGIT_STEPS:
+                extra[f'logits_{t}'] = lg.numpy()
+        rec['min_margin'].append(mm); rec['min_margin_k'].append(mk); rec['min_margin_logits'].append(ml)
+        prev = state
+        if t % 32 == 0:
+            print(f'    t={t} K={len(K)} A={A} E={len(state)}  {time.time() - t0:.0f}s', flush=True)
+        return out
+    model.p_sample = spy
+    import io
+    import contextlib
+    with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+        res = model.sample(len(graphs))
+    steps = len(rec['A'])
+    assert steps == T
+    save(f'trajbig_{case}.npz', T=T, max_degree=dmax, uniform_seed=useed + 3,
+         K=np.concatenate(rec['K']), K_off=np.array(rec['K_off'], np.int64),
+         delta=np.concatenate(rec['delta']), delta_off=np.array(rec['delta_off'], np.int64),
+         A=np.array(rec['A'], np.int64), E=np.array(rec['E'], np.int64),
+         min_margin=np.array(rec['min_margin'], np.float32), min_margin_k=np.array(rec['min_margin_k'], np.int64),
+         min_margin_logits=np.stack(rec['min_margin_logits']).astype(np.float32),
+         edge_index=res.edge_index, **extra)
+    print(f'    final edges {res.edge_index.shape[1]}, decisions {int(np.sum(rec["A"]))}, '
+          f'smallest |margin| {float(np.min(np.abs(rec["min_margin"]))):.3e}')
+
+
 def synth_deg(g):
     from edgehip import synth
     return synth.degrees(g['n'], g['edges']).astype(np.float32)
@@ -366,6 +452,12 @@ def synth_deg(g):
 if __name__ == '__main__':
     torch.manual_seed(0)
     real_rand_like = torch.rand_like
+    if len(sys.argv) > 1 and sys.argv[1] == 'trajbig':
+        try:
+            gen_traj_big('polblogs1')
+        finally:
+            torch.rand_like = real_rand_like
+        sys.exit(0)
     try:
         gen_schedule()
         gen_posterior()
