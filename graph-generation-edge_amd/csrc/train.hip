@@ -853,6 +853,52 @@ extern "C" int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float
 }
 
 // ================================================================================================
+// I2. dropout (torch.nn.Dropout in training mode, layers/layers.py:286,357,361) on [Nn,64] rows.
+//     y = x * keep / (1 - p).  keep comes from supplied 0/1 masks (parity runs: the reference is patched to use the
+//     same masks) or from Philox keyed (seed; graph global id, node, channel group, slot), so that a graph's masks do
+//     not depend on how the batch is sharded.  The backward is the same op applied to the gradient.
+//     One thread = 4 consecutive channels of one node.
+// ------------------------------------------------------------------------------------------------
+#define EH_STREAM_DROPOUT 5
+__global__ __launch_bounds__(256) void k_tr_dropout(edgehip_layout L, const float* __restrict__ x, float p, float scale,
+                                                    uint64_t seed, int slot, const uint8_t* __restrict__ mask,
+                                                    float* __restrict__ y) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (node, 4-channel group)
+    const int64_t node = idx >> 4;
+    const int c4 = (int)(idx & 15);
+    if (node >= L.num_nodes) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + node * 64 + c4 * 4);
+    float k[4];
+    if (mask) {
+        const uint8_t* m = mask + node * 64 + c4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[e] = m[e] ? scale : 0.f;
+    } else {
+        const int b = L.node_graph[node];
+        const uint32_t li = (uint32_t)(node - L.node_ptr[b]);
+        const eh_u4 r = eh_philox(seed, li * 16u + (uint32_t)c4, (uint32_t)slot, (uint32_t)(L.gid_base + b), EH_STREAM_DROPOUT);
+        k[0] = eh_u24(r.x) >= p ? scale : 0.f; k[1] = eh_u24(r.y) >= p ? scale : 0.f;
+        k[2] = eh_u24(r.z) >= p ? scale : 0.f; k[3] = eh_u24(r.w) >= p ? scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(y + node * 64 + c4 * 4) = f32x4{v[0] * k[0], v[1] * k[1], v[2] * k[2], v[3] * k[3]};
+}
+
+static bool tr_dp_on(const edgehip_dropout* dp) { return dp != nullptr && dp->p > 0.f; }
+
+extern "C" int edgehip_dropout_fwd(const edgehip_layout* L, const float* x, const edgehip_dropout* dp, int32_t slot,
+                                   float* y, void* stream) {
+    EH_CHECK_ARG(L && x && y && dp && slot >= 0 && slot < 2 * EDGEHIP_MAX_LAYERS);
+    if (!(dp->p >= 0.f && dp->p < 1.f)) return EDGEHIP_ERR_ARG;
+    if (L->num_nodes == 0) return EDGEHIP_OK;
+    const float scale = 1.0f / (1.0f - dp->p);
+    const uint8_t* mask = dp->masks ? dp->masks + (size_t)slot * (size_t)L->num_nodes * 64 : nullptr;
+    EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_dropout, TR_GRID((int64_t)L->num_nodes * 16, 256), dim3(256), 0,
+                       eh_stream(stream), *L, x, dp->p, scale, dp->seed, slot, mask, y));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
+// ================================================================================================
 // J. The whole differentiable network in two calls.
 //    edgehip_train_forward / edgehip_train_backward queue the SAME ops as above, in the order of
 //    TGNN_degree_guided.forward (layers/layers.py:315-383), from one host call each: ~190 / ~330 launches are
@@ -872,6 +918,7 @@ struct tr_bump {
 struct tr_plan {
     // saved by the forward
     float *X0, *a0, *hs[EDGEHIP_MAX_LAYERS + 1];
+    float* hd[EDGEHIP_MAX_LAYERS + 1];      // dropout(hs[i]) = the GRU hidden state carried into layer i (layers.py:361); hd[0] = hs[0]
     float *pe, *m1, *m1s, *m2, *mt;
     float *gin[EDGEHIP_MAX_LAYERS + 1], *g1[EDGEHIP_MAX_LAYERS + 1], *g1s[EDGEHIP_MAX_LAYERS + 1], *cx[EDGEHIP_MAX_LAYERS + 1];
     float *tl[EDGEHIP_MAX_LAYERS], *x[EDGEHIP_MAX_LAYERS], *q[EDGEHIP_MAX_LAYERS], *k[EDGEHIP_MAX_LAYERS], *v[EDGEHIP_MAX_LAYERS];
@@ -901,6 +948,8 @@ static void tr_make_plan(tr_plan& p, const edgehip_layout* L, const edgehip_gnn_
     for (size_t i = 0; i < nl; ++i) hmax = P->heads[i] > hmax ? P->heads[i] : hmax;
     p.X0 = b.take(Nn * 192); p.a0 = b.take(Nn * 64);
     for (size_t i = 0; i <= nl; ++i) p.hs[i] = b.take(Nn * 64);
+    p.hd[0] = p.hs[0]; p.hd[nl] = nullptr;
+    for (size_t i = 1; i < nl; ++i) p.hd[i] = b.take(Nn * 64);
     p.pe = b.take(B * 64); p.m1 = b.take(B * 256); p.m1s = b.take(B * 256); p.m2 = b.take(B * 64); p.mt = b.take(B * 64);
     for (size_t i = 0; i <= nl; ++i) {
         p.gin[i] = b.take(B * 64); p.g1[i] = b.take(B * 256); p.g1s[i] = b.take(B * 256); p.cx[i] = b.take(B * 64);
@@ -1146,7 +1195,9 @@ static int tr_global_bwd(const edgehip_gnn_params* G, const tr_plan& p, int j, i
 // that fixes the workspace layout; a caller can queue it before it knows how many pairs the step has.
 static int tr_forward_nodes(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t, const int32_t* deg_t,
                             const int32_t* d0, const uint8_t* flags, const int32_t* t_graph, int64_t A_cap, void* ws,
-                            size_t ws_bytes, void* stream) {
+                            size_t ws_bytes, void* stream, const edgehip_dropout* dp = nullptr) {
+    const bool drop = tr_dp_on(dp);
+    if (dp && !(dp->p >= 0.f && dp->p < 1.f)) return EDGEHIP_ERR_ARG;
     EH_CHECK_ARG(L && P && adj_t && deg_t && d0 && flags && t_graph && ws && A_cap >= 0);
     TR_RC(tr_check_net(P));
     if (ws_bytes < edgehip_train_workspace_bytes(L, P, A_cap)) return EDGEHIP_ERR_WORKSPACE;
@@ -1183,13 +1234,17 @@ static int tr_forward_nodes(const edgehip_layout* L, const edgehip_gnn_params* P
                                   tr_desc_lin(p.x[i], Nn, 128, P->key_w[i], P->key_b[i], hd, p.k[i], nullptr),
                                   tr_desc_lin(p.x[i], Nn, 128, P->value_w[i], P->value_b[i], hd, p.v[i], nullptr),
                                   tr_desc_lin(p.x[i], Nn, 128, P->skip_w[i], P->skip_b[i], 64, p.sk[i], nullptr),
-                                  tr_desc_lin(p.hs[i], Nn, 64, P->gru_w_hh, P->gru_b_hh, 192, p.gh[i], nullptr)};
+                                  tr_desc_lin(drop ? p.hd[i] : p.hs[i], Nn, 64, P->gru_w_hh, P->gru_b_hh, 192, p.gh[i], nullptr)};
             TR_RC(eh_launch_gemm_group(ds, 5, s));
         }
         TR_RC(edgehip_attn_fwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.sk[i], p.conv[i], p.O[i], p.lse[i], stream));
         TR_RC(edgehip_act_fwd(1, p.conv[i], Nn * 64, p.xs[i], stream));
+        if (drop) TR_RC(edgehip_dropout_fwd(L, p.xs[i], dp, 2 * i, p.xs[i], stream));                  // layers.py:357
         TR_RC(tr_lin(p.xs[i], Nn, 64, P->gru_w_ih, P->gru_b_ih, 192, p.gi[i], nullptr, s));
-        TR_RC(edgehip_gru_gate_fwd(p.gi[i], p.gh[i], p.hs[i], Nn, p.hs[i + 1], stream));
+        TR_RC(edgehip_gru_gate_fwd(p.gi[i], p.gh[i], drop ? p.hd[i] : p.hs[i], Nn, p.hs[i + 1], stream));
+        // layers.py:361: only the hidden state carried to the next layer is dropped, not the GRU output `nodes`
+        // (the last layer's dropped state is never read)
+        if (drop && i + 1 < nl) TR_RC(edgehip_dropout_fwd(L, p.hs[i + 1], dp, 2 * i + 1, p.hd[i + 1], stream));
         TR_RC(edgehip_assemble_fwd(L, p.hs[i + 1], nullptr, p.cx[i], nullptr, 64, p.cin[i], stream));
         TR_RC(tr_lin(p.cin[i], Nn, 128, P->context_w0, P->context_b0, 256, p.c1[i], p.c1s[i], s));
         TR_RC(tr_lin(p.c1s[i], Nn, 256, P->context_w2, P->context_b2, 64, p.nctx[i], nullptr, s));
@@ -1227,6 +1282,12 @@ extern "C" int edgehip_train_forward_nodes(const edgehip_layout* L, const edgehi
                                            const int32_t* t_graph, int64_t A_cap, void* ws, size_t ws_bytes, void* stream) {
     return tr_forward_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, A_cap, ws, ws_bytes, stream);
 }
+extern "C" int edgehip_train_forward_nodes_dp(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                              const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                              const int32_t* t_graph, int64_t A_cap, const edgehip_dropout* dp, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    return tr_forward_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, A_cap, ws, ws_bytes, stream, dp);
+}
 extern "C" int edgehip_train_forward_pairs(const edgehip_layout* L, const edgehip_gnn_params* P, const int64_t* row,
                                            const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
                                            const int32_t* pair_graph, float* ce_graph, float* logits, void* ws,
@@ -1253,10 +1314,31 @@ extern "C" int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn
                                       const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream) {
     return edgehip_train_backward_cap(L, P, G, adj_t, deg_t, d0, flags, row, col, A, A, tgt, pair_graph, gce, ws, ws_bytes, stream);
 }
+static int tr_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                       const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                       const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                       const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream,
+                       const edgehip_dropout* dp);
 extern "C" int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
                                           const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                                           const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
                                           const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream) {
+    return tr_backward(L, P, G, adj_t, deg_t, d0, flags, row, col, A, A_cap, tgt, pair_graph, gce, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int edgehip_train_backward_dp(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                                         const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                                         const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                                         const int32_t* pair_graph, const float* gce, const edgehip_dropout* dp, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    return tr_backward(L, P, G, adj_t, deg_t, d0, flags, row, col, A, A_cap, tgt, pair_graph, gce, ws, ws_bytes, stream, dp);
+}
+static int tr_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                       const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                       const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                       const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream,
+                       const edgehip_dropout* dp) {
+    const bool drop = tr_dp_on(dp);
+    if (dp && !(dp->p >= 0.f && dp->p < 1.f)) return EDGEHIP_ERR_ARG;
     EH_CHECK_ARG(L && P && G && adj_t && deg_t && d0 && flags && gce && ws && A >= 0 && A <= A_cap);
     EH_CHECK_ARG(A == 0 || (row && col && tgt && pair_graph));
     TR_RC(tr_check_net(P));
@@ -1323,13 +1405,20 @@ extern "C" int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip
                            (float*)nullptr, ds));
         EH_LAUNCH_CHECK();
         // GRU (layers.py:360)
-        TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], p.hs[i], dh, Nn, p.dgi[i], p.dgh[i], dh2, stream));
+        const float* hid = drop ? p.hd[i] : p.hs[i];                                 // the hidden state the GRU saw
+        TR_RC(edgehip_gru_gate_bwd(p.gi[i], p.gh[i], hid, dh, Nn, p.dgi[i], p.dgh[i], dh2, stream));
         TR_RC(W.dw(p.dgi[i], p.xs[i], Nn, 192, 64, G->gru_w_ih, G->gru_b_ih));
-        TR_RC(W.dw(p.dgh[i], p.hs[i], Nn, 192, 64, G->gru_w_hh, G->gru_b_hh));
+        TR_RC(W.dw(p.dgh[i], hid, Nn, 192, 64, G->gru_w_hh, G->gru_b_hh));
         {
             eh_gemm_desc ds[2] = {tr_desc_dx(p.dgi[i], Nn, 192, p.wt_ih, 64, p.dconv[i], 0, p.conv[i]),   // through act{i}
                                   tr_desc_dx(p.dgh[i], Nn, 192, p.wt_hh, 64, dh2, 1)};
             TR_RC(eh_launch_gemm_group(ds, 2, s));
+        }
+        if (drop) {
+            // d conv = d xs * keep/(1-p) * SiLU'(conv): the mask factor commutes with the SiLU' of the epilogue above;
+            // dh2 so far is the gradient of the DROPPED hidden state hd[i]: back through its mask to hs[i] (i > 0)
+            TR_RC(edgehip_dropout_fwd(L, p.dconv[i], dp, 2 * i, p.dconv[i], stream));
+            if (i > 0) TR_RC(edgehip_dropout_fwd(L, dh2, dp, 2 * (i - 1) + 1, dh2, stream));
         }
         // TransformerConv (layers.py:354)
         TR_RC(edgehip_attn_bwd(L, adj_t, h, p.q[i], p.k[i], p.v[i], p.O[i], p.lse[i], p.dconv[i], p.Dbuf, p.dq[i], p.dk[i],

@@ -39,6 +39,10 @@ class Rng(C.Structure):
     _fields_ = [('seed', C.c_uint64)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [('p', C.c_float), ('reserved', C.c_int32), ('seed', C.c_uint64), ('masks', vp)]
+
+
 _PL = vp * MAX_LAYERS
 
 
@@ -108,6 +112,11 @@ EXPORTS = {
     'edgehip_train_forward_nodes': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, C.c_int64, vp, C.c_size_t, vp],
     'edgehip_train_forward_pairs': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp,
                                     C.c_size_t, vp],
+    'edgehip_dropout_fwd': [C.POINTER(Layout), vp, C.POINTER(Dropout), C.c_int32, vp, vp],
+    'edgehip_train_forward_nodes_dp': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, C.c_int64,
+                                       C.POINTER(Dropout), vp, C.c_size_t, vp],
+    'edgehip_train_backward_dp': [C.POINTER(Layout), C.POINTER(GnnParams), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp,
+                                  C.c_int64, C.c_int64, vp, vp, vp, C.POINTER(Dropout), vp, C.c_size_t, vp],
     'edgehip_train_backward_cap': [C.POINTER(Layout), C.POINTER(GnnParams), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp,
                                    C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_size_t, vp],
 }

@@ -624,7 +624,10 @@ class BinomialDiffusionActive(nn.Module):
         return out
 
     # ---- a18, a21 : loss -------------------------------------------------------------------------
-    def log_prob(self, batch, t=None, pt=None, u_tm1=None, u_t=None, want=None):
+    def log_prob(self, batch, t=None, pt=None, u_tm1=None, u_t=None, want=None, dropout_masks=None):
+        """dropout_masks (parity runs): uint8 [2*layers, Nn, 64] keep-masks used instead of generated ones when the
+        network is in training mode with --dp_rate > 0."""
+        self._dropout_masks = dropout_masks
         if self.loss_type != 'vb_ce_xt_prescribred_st':
             if self.loss_type in ('vb_kl', 'vb_ce_xt', 'vb_ce_xt_kl_st', 'vb_ce_xt_ce_st'):
                 raise NotImplementedError(f"loss_type '{self.loss_type}' is outside the accelerated hot path")
@@ -667,23 +670,37 @@ class BinomialDiffusionActive(nn.Module):
         self._set_offsets(batch)
         st['adj_t'], st['adj_tm1'], st['deg_tm1'], st['t_graph'] = adj_t, adj_tm1, deg_tm1, t_graph
         net = self._denoise_fn
-        if differentiable:
+        # torch.nn.Dropout follows the MODULE's mode (layers.py:286,357,361): active in train(), also under no_grad
+        dp = None
+        if net.training and net.dropout_p > 0:
+            dp = capi.Dropout()
+            dp.p, dp.seed = float(net.dropout_p), self._next_seed()
+            masks = getattr(self, '_dropout_masks', None)
+            if masks is not None:
+                assert masks.dtype == torch.uint8 and masks.is_contiguous() and masks.device == dev and \
+                    tuple(masks.shape) == (2 * len(net.num_heads), batch.num_nodes, 64)
+                dp.masks = masks.data_ptr()
+                dp._keep = masks
+        if differentiable or dp is not None:      # the op-by-op / fused TRAINING form (the inference kernels have no dropout)
             from . import train
             net.pos_emb(dev)
-            net.weights_changed()           # an optimizer step may follow this loss (see weights_changed)
+            if differentiable:
+                net.weights_changed()       # an optimizer step may follow this loss (see weights_changed)
             counts = None
             if getattr(self, 'train_form', 'fused') != 'ops':
                 # the node part of the network needs no active pairs: it is queued before the step's only host sync
                 # (the pair counts), read back on a side stream behind the offsets kernel
                 after = torch.cuda.Event()
                 after.record(torch.cuda.current_stream(dev))
-                train.prelaunch_nodes(net, batch, adj_t, st['deg_t'], st['flags'], t_graph)
+                train.prelaunch_nodes(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, dp)
                 counts = self._read_counts(batch, after)
             self.materialize_actives(batch, counts)
             row, col = batch.active_row, batch.active_col
             tgt, pair_graph = train.pair_targets(batch, adj_tm1, row, col)
             fwd = train.tgnn_ce_forward if getattr(self, 'train_form', 'fused') == 'ops' else train.tgnn_ce_fused
-            ce, logits = fwd(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, row, col, tgt, pair_graph)
+            ce, logits = fwd(net, batch, adj_t, st['deg_t'], st['flags'], t_graph, row, col, tgt, pair_graph, dp)
+            if not ce.requires_grad:
+                batch._train_ws_busy = False      # no backward will come to release the workspace
             npairs = batch.edges_per_graph.to(dev).float()
             n_act = (st['aptr'][1:] - st['aptr'][:-1]).float()
             kl = ce + 6.9078e-29 * (npairs - n_act) + 6.9078e-29 * npairs          # active.py:176-181

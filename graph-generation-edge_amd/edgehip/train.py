@@ -262,6 +262,26 @@ class _EdgeCE(Function):
         return de2, dW4, db4, None, None, None
 
 
+class _Dropout(Function):
+    """torch.nn.Dropout in training mode (layers.py:357,361); the backward is the same masked scaling."""
+
+    @staticmethod
+    def forward(ctx, x, L, dp, slot):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        capi.check(lib.edgehip_dropout_fwd(byref(L), x.data_ptr(), byref(dp), slot, y.data_ptr(), _s()), 'dropout_fwd')
+        ctx.args = (L, dp, slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L, dp, slot = ctx.args
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        capi.check(lib.edgehip_dropout_fwd(byref(L), dy.data_ptr(), byref(dp), slot, dx.data_ptr(), _s()), 'dropout_bwd')
+        return dx, None, None, None
+
+
 def linear(x, m):
     return _Linear.apply(x, m.weight, m.bias)
 
@@ -284,7 +304,7 @@ def pair_targets(batch, adj_tm1, row, col):
     return tgt, pg
 
 
-def tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph):
+def tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, dp=None):
     """Differentiable TGNN_degree_guided.forward on the active pairs (row, col) followed by the per-graph
     cross-entropy against `tgt`.  Returns (ce_graph [B] with grad, logits [A,2])."""
     L = batch.layout
@@ -293,7 +313,8 @@ def tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pai
     nodes0 = act(linear(X0, net.node_in[0]))                                   # layers.py:335-336
     pe = net._pos_emb.index_select(0, t_graph.long())                          # table lookup, no grad
     mt = act(_mlp2(pe, net.mlp), MISH)                                         # layers.py:338-339, :31-34
-    h = nodes0
+    h = hid = nodes0                         # h: GRU output `nodes`; hid: the hidden state carried on (dropped, :361)
+    drop = dp is not None and dp.p > 0
     cx = _mlp2(_SegmentMean.apply(nodes0, None, L), net.global_mlp)            # layers.py:342-343
     for i, heads in enumerate(net.num_heads):
         tl = linear(mt, net.layers[f'time{i}'].linear)
@@ -302,9 +323,12 @@ def tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pai
         conv = _Attention.apply(linear(x, cv.lin_query), linear(x, cv.lin_key), linear(x, cv.lin_value),
                                 linear(x, cv.lin_skip), L, adj_t, heads)
         xs = act(conv)
+        if drop:
+            xs = _Dropout.apply(xs, L, dp, 2 * i)                              # :357
         gi = _Linear.apply(xs, net.gru.weight_ih_l0, net.gru.bias_ih_l0)
-        gh = _Linear.apply(h, net.gru.weight_hh_l0, net.gru.bias_hh_l0)
-        h = _GruGate.apply(gi, gh, h)
+        gh = _Linear.apply(hid, net.gru.weight_hh_l0, net.gru.bias_hh_l0)
+        h = _GruGate.apply(gi, gh, hid)
+        hid = _Dropout.apply(h, L, dp, 2 * i + 1) if drop and i + 1 < len(net.num_heads) else h   # :361
         cin = _Assemble.apply(h, None, cx, None, L)                            # cat[nodes, contexts]  :366
         nctx = _mlp2(cin, net.context_mlp)
         cx = _mlp2(_SegmentMean.apply(nctx, cx, L), net.global_mlp)            # :367-368
@@ -385,7 +409,18 @@ def _take_workspace(batch, L, P, cap, dev):
     return ws
 
 
-def prelaunch_nodes(net, batch, adj_t, deg_t, flags, t_graph):
+def _fwd_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, cap, ws, dp):
+    if dp is not None and dp.p > 0:
+        capi.check(lib.edgehip_train_forward_nodes_dp(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
+                                                      flags.data_ptr(), t_graph.data_ptr(), cap, byref(dp), ws.data_ptr(),
+                                                      ws.numel(), _s()), 'train_forward_nodes_dp')
+    else:
+        capi.check(lib.edgehip_train_forward_nodes(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
+                                                   flags.data_ptr(), t_graph.data_ptr(), cap, ws.data_ptr(), ws.numel(),
+                                                   _s()), 'train_forward_nodes')
+
+
+def prelaunch_nodes(net, batch, adj_t, deg_t, flags, t_graph, dp=None):
     """Queues the node part of the fused forward NOW, before the caller has read the number of active pairs back
     from the device (the step's only host sync): the device works through it while the host enumerates the pairs.
     Needs the pair capacity of an earlier step on this batch; returns False (nothing queued) without one."""
@@ -396,16 +431,14 @@ def prelaunch_nodes(net, batch, adj_t, deg_t, flags, t_graph):
         return False
     L, P = batch.layout, net.raw_params()
     ws = _take_workspace(batch, L, P, cap, adj_t.device)
-    capi.check(lib.edgehip_train_forward_nodes(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(),
-                                               batch.degree_i32.data_ptr(), flags.data_ptr(), t_graph.data_ptr(), cap,
-                                               ws.data_ptr(), ws.numel(), _s()), 'train_forward_nodes')
+    _fwd_nodes(L, P, adj_t, deg_t, batch.degree_i32, flags, t_graph, cap, ws, dp)
     batch._train_pre = dict(ws=ws, cap=cap, adj=adj_t.data_ptr())
     return True
 
 
 class _FusedNet(Function):
     @staticmethod
-    def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, arena_params, *inputs):
+    def forward(ctx, net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, dp, arena_params, *inputs):
         # arena_params: the parameters when their gradients go straight into the active GradArena; `inputs` is then a
         # single anchor tensor (autograd only has to call backward: an apply() over 86 parameter inputs costs ~0.25 ms
         # of host time each way, right after the step's only host sync).  Otherwise `inputs` are the parameters.
@@ -431,13 +464,12 @@ class _FusedNet(Function):
             if A > cap:
                 cap = batch._train_cap = int(A * 1.3) + 4096
             ws = _take_workspace(batch, L, P, cap, dev)
-            capi.check(lib.edgehip_train_forward_nodes(byref(L), byref(P), adj_t.data_ptr(), deg_t.data_ptr(), d0.data_ptr(),
-                                                       flags.data_ptr(), t_graph.data_ptr(), cap, ws.data_ptr(), ws.numel(),
-                                                       _s()), 'train_forward_nodes')
+            _fwd_nodes(L, P, adj_t, deg_t, d0, flags, t_graph, cap, ws, dp)
         capi.check(lib.edgehip_train_forward_pairs(byref(L), byref(P), capi.ptr(row), capi.ptr(col), A, cap, capi.ptr(tgt),
                                                    capi.ptr(pair_graph), ce.data_ptr(), logits.data_ptr(), ws.data_ptr(),
                                                    ws.numel(), _s()), 'train_forward_pairs')
         ctx.cap = cap
+        ctx.dp = dp
         ctx.args = (net, batch, P, adj_t, deg_t, d0, flags, row, col, tgt, pair_graph, ws, params, arena_params is not None)
         ctx.mark_non_differentiable(logits)
         return ce, logits
@@ -465,30 +497,32 @@ class _FusedNet(Function):
         G = capi.GnnParams()
         net.fill_struct(G, address)
         gce = gce.contiguous()
-        capi.check(lib.edgehip_train_backward_cap(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
-                                                  d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
-                                                  ctx.cap, capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(), ws.data_ptr(),
-                                                  ws.numel(), _s()), 'train_backward')
+        dp = ctx.dp
+        capi.check(lib.edgehip_train_backward_dp(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
+                                                 d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
+                                                 ctx.cap, capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(),
+                                                 byref(dp) if dp is not None else None, ws.data_ptr(),
+                                                 ws.numel(), _s()), 'train_backward')
         if ws is getattr(batch, '_train_ws', None):
             batch._train_ws_busy = False
-        head = (None,) * 11
+        head = (None,) * 12
         if direct:
             return head + (None,) * (1 if anchored else len(params))
         used = {prm.data_ptr() for _, _, prm in net.param_slots()}
         return head + tuple(g if p.data_ptr() in used else None for p, g in zip(params, grads))
 
 
-def tgnn_ce_fused(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph):
+def tgnn_ce_fused(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, dp=None):
     """Same contract as tgnn_ce_forward, one autograd node."""
     params = [p for p in net.parameters() if p.requires_grad]
     if len(params) != sum(1 for _ in net.parameters()):
         # frozen parameters: the op-by-op form lets autograd skip them
-        return tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph)
+        return tgnn_ce_forward(net, batch, adj_t, deg_t, flags, t_graph, row, col, tgt, pair_graph, dp)
     arena = _ACTIVE_ARENA[0]
     if arena is not None and arena.matches(params):
         anchor = getattr(net, '_grad_anchor', None)
         if anchor is None or anchor.device != adj_t.device:
             anchor = net._grad_anchor = torch.zeros((), device=adj_t.device, requires_grad=True)
-        return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph,
+        return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, dp,
                                tuple(params), anchor)
-    return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, None, *params)
+    return _FusedNet.apply(net, batch, adj_t, deg_t, flags, t_graph.contiguous(), row, col, tgt, pair_graph, dp, None, *params)

@@ -348,6 +348,21 @@ int edgehip_edge_ce_fwd(const float* e2, const float* W4, const float* b4, const
 int edgehip_edge_ce_bwd(const float* e2, const float* W4, const float* b4, const uint8_t* tgt, const int32_t* pair_graph,
                         const float* gkl, int64_t A, float* de2, float* dW4, float* db4, void* stream);
 
+/* ---- dropout of the training forward ----------------------------------------------------------------
+ * replaces: self.dropout = torch.nn.Dropout(p=dropout) in training mode, layers/layers.py:286, applied to the
+ *           conv output (:357, slot 2i) and to the GRU hidden state carried to the next layer (:361, slot 2i+1)
+ * y[Nn,64] = x * keep / (1 - p) (in place allowed).  keep: dp->masks ([2*num_layers][Nn][64] uint8 0/1, slot-major;
+ * parity runs give the reference the same masks) or, when masks == NULL, Philox keyed (seed; graph global id, node,
+ * channel group, slot): shard-invariant, reproducible.  The backward of the op is the op itself on the gradient. */
+typedef struct edgehip_dropout {
+    float p;                  /* drop probability, 0 <= p < 1 (0: the op is the identity) */
+    int32_t reserved;
+    uint64_t seed;
+    const uint8_t* masks;     /* device pointer or NULL */
+} edgehip_dropout;
+int edgehip_dropout_fwd(const edgehip_layout* L, const float* x, const edgehip_dropout* dp, int32_t slot, float* y,
+                        void* stream);
+
 /* ---- the whole differentiable network in two calls ------------------------------------------------
  * replaces: TGNN_degree_guided.forward layers/layers.py:315-383 + _compute_MC_KL_joint
  *           diffusion_binomial_active.py:157-175 under autograd, and loss.backward() through them
@@ -381,6 +396,16 @@ int edgehip_train_backward_cap(const edgehip_layout* L, const edgehip_gnn_params
                                const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                                const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
                                const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream);
+/* The node part and the backward with training-mode dropout (--dp_rate > 0, README.md:49,79); dp == NULL or
+ * dp->p == 0 is edgehip_train_forward_nodes / edgehip_train_backward_cap.  The same `dp` must be given to both. */
+int edgehip_train_forward_nodes_dp(const edgehip_layout* L, const edgehip_gnn_params* P, const uint32_t* adj_t,
+                                   const int32_t* deg_t, const int32_t* d0, const uint8_t* flags, const int32_t* t_graph,
+                                   int64_t A_cap, const edgehip_dropout* dp, void* ws, size_t ws_bytes, void* stream);
+int edgehip_train_backward_dp(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
+                              const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
+                              const int64_t* row, const int64_t* col, int64_t A, int64_t A_cap, const uint8_t* tgt,
+                              const int32_t* pair_graph, const float* gce, const edgehip_dropout* dp, void* ws,
+                              size_t ws_bytes, void* stream);
 int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P, const edgehip_gnn_params* G,
                            const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                            const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,

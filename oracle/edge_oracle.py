@@ -399,9 +399,17 @@ def _mlp2(p, name, x):
                     p[f'{name}.2.weight'], p[f'{name}.2.bias'])
 
 
+def mask_dropout(masks, p):
+    """torch.nn.Dropout(p) in training mode with SUPPLIED keep-masks (layers.py:286,357,361): slot 2i is the mask of
+    layer i's conv output, slot 2i+1 the one of its GRU hidden state; y = x * keep / (1 - p)."""
+    scale = 1.0 / (1.0 - p)
+    return lambda slot, x: x * (torch.as_tensor(masks[slot], dtype=x.dtype) * scale)
+
+
 def tgnn_forward(p, bt, t_node, max_degree, num_steps, num_heads=(8, 8, 8, 8, 1), dim=64,
-                 return_intermediates=False):
-    """TGNN_degree_guided.forward, eval mode / dropout 0 (layers.py:315-383).
+                 return_intermediates=False, dropout=None):
+    """TGNN_degree_guided.forward (layers.py:315-383).  dropout: None (eval mode / --dp_rate 0) or a callable
+    (slot, x) -> x' standing for self.dropout in training mode (see mask_dropout).
 
     Returns edge logits [A,2] for bt.active_edge_indices (row k <-> k-th active pair)."""
     bits = bt.log_full_edge_attr_t.argmax(-1)
@@ -432,8 +440,12 @@ def tgnn_forward(p, bt, t_node, max_degree, num_steps, num_heads=(8, 8, 8, 8, 1)
                              p[c + 'key.bias'], p[c + 'value.weight'], p[c + 'value.bias'],
                              p[c + 'skip.weight'], p[c + 'skip.bias'], nh, dim)
         x = F.silu(x)                                                               # norm 'None' = identity
+        if dropout is not None:
+            x = dropout(2 * i, x)                                                   # :357
         h = gru_cell(x, h, p['gru.weight_ih_l0'], p['gru.weight_hh_l0'], p['gru.bias_ih_l0'], p['gru.bias_hh_l0'])
-        nodes = h
+        nodes = h                                                                   # :360, GRU output (not dropped)
+        if dropout is not None:
+            h = dropout(2 * i + 1, h)                                               # :361, the carried hidden state only
         nctx = _mlp2(p, 'context_mlp', torch.cat([nodes, ctx], -1))                 # :366
         ctx = _mlp2(p, 'global_mlp', scatter_mean(ctx + nctx, bt.batch, bt.num_graphs))
         ctx = ctx.repeat_interleave(bt.nodes_per_graph, dim=0)
@@ -473,10 +485,12 @@ class EdgeOracle:
         self.sched = make_schedule(T, schedule, final_prob_edge)
         self.Lt_history = torch.zeros(T)
         self.Lt_count = torch.zeros(T)
+        self.dropout = None          # training-mode dropout as a callable (slot, x) -> x', see mask_dropout
         self.logit_override = None   # optional callable(step_t, bt) -> logits, for tie-free trajectory checks
 
     def denoise(self, bt, t_node):
-        return tgnn_forward(self.p, bt, t_node, self.max_degree, self.T, self.num_heads, self.dim)
+        return tgnn_forward(self.p, bt, t_node, self.max_degree, self.T, self.num_heads, self.dim,
+                            dropout=self.dropout)
 
     def p_sample(self, bt, t_node, tape, record=None):
         """diffusion_binomial_active.py:72-90."""

@@ -64,3 +64,10 @@ CASES = {
     'ragged': (ragged_graphs, 48, 102, 202),
     'polblogs1': (polblogs_graph, 512, 103, 203),
 }
+
+
+def dropout_masks(useed, num_nodes, p, layers=len(HEADS), dim=DIM):
+    """Keep-masks of the training-mode dropout, one [Nn, dim] 0/1 array per call of `self.dropout` in
+    TGNN_degree_guided.forward (layers.py:357,361): slot 2i = conv output of layer i, slot 2i+1 = its GRU hidden."""
+    rng = np.random.default_rng(useed + 7)
+    return [torch.from_numpy((rng.random((num_nodes, dim)) >= p).astype(np.uint8)) for _ in range(2 * layers)]

@@ -111,11 +111,33 @@ class Replay:
         return self.tape.take(x.shape).clone()
 
 
-def build_ref_model(params, T, max_degree, schedule='linear'):
+class SuppliedMaskDropout(torch.nn.Module):
+    """Stands in for the reference network's `self.dropout = torch.nn.Dropout(p)` (layers.py:286): same place in the
+    module tree, same calls (layers.py:357,361), same arithmetic y = x * keep / (1 - p) in training mode, identity in
+    eval mode - but the Bernoulli keep-masks are SUPPLIED (call k of a forward takes masks[k]) so that the GPU
+    path can be given the very same masks.  A forward pre-hook on the network rewinds the call counter."""
+
+    def __init__(self, p, masks):
+        super().__init__()
+        self.p, self.masks, self.k = p, masks, 0
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        m = self.masks[self.k].to(x.dtype).reshape(x.shape)
+        self.k += 1
+        return x * (m * (1.0 / (1.0 - self.p)))
+
+
+def build_ref_model(params, T, max_degree, schedule='linear', dropout=0., masks=None):
     net = TGNN_degree_guided(max_degree=max_degree, num_node_classes=2, num_edge_classes=2, dim=cases.DIM,
-                             num_steps=T, num_heads=list(cases.HEADS), dropout=0., norm='None', gru=True,
+                             num_steps=T, num_heads=list(cases.HEADS), dropout=dropout, norm='None', gru=True,
                              degree=True, augmented_features={}, return_node_class=False)
     missing = net.load_state_dict(params, strict=True)
+    if dropout > 0:
+        assert isinstance(net.dropout, torch.nn.Dropout) and net.dropout.p == dropout
+        net.dropout = SuppliedMaskDropout(dropout, masks)
+        net.register_forward_pre_hook(lambda mod, inp: setattr(mod.dropout, 'k', 0))
     sched = {'linear': ref_base.linear_beta_schedule, 'cosine': ref_base.cosine_beta_schedule,
              'Tt1': ref_base.Tt1_beta_schedule}[schedule]
     m = BinomialDiffusionActive(2, 2, None, net, timesteps=T, loss_type='vb_ce_xt_prescribred_st',
@@ -251,14 +273,15 @@ def gen_step(case, t_step):
     print(f'    E_t={len(xt_before)} K={len(rb.active_node_indices)} A={A} E_after={len(ones_idx(out_edge))}')
 
 
-def gen_loss(case, t_list, tag=''):
-    print(f'train loss: {case} t={t_list}')
+def gen_loss(case, t_list, tag='', dp=0.):
+    print(f'train loss: {case} t={t_list} dp={dp}')
     builder, T, wseed, useed = cases.CASES[case]
     graphs = builder()
     dmax = cases.max_degree_of(graphs)
     params = orc.random_tgnn_params(wseed)
-    model = build_ref_model(params, T, dmax)
-    model.train()          # dropout is 0; selects _train_loss (diffusion_base.py:183-187)
+    masks = cases.dropout_masks(useed, sum(g['n'] for g in graphs), dp) if dp > 0 else None
+    model = build_ref_model(params, T, dmax, dropout=dp, masks=masks)
+    model.train()          # selects _train_loss (diffusion_base.py:183-187) and, with dp > 0, activates the dropout
     rng = np.random.default_rng(useed + 1)
     rb = ref_batch(graphs, torch.int64)       # training batches carry int64 degree (data_utils.py:62)
     ob = orc.make_batch(graphs, torch.int64)
@@ -275,6 +298,8 @@ def gen_loss(case, t_list, tag=''):
         prior = model._kl_prior(rb)
         logits = model._denoise_fn(rb, t.repeat_interleave(rb.nodes_per_graph), None)[1]
     o = orc.EdgeOracle(params, T, dmax)
+    if dp > 0:
+        o.dropout = orc.mask_dropout(masks, dp)
     rec = {}
     with torch.no_grad():
         onv = o.loss(ob, t, pt, orc.UniformTape(us), training=True, record=rec)
@@ -452,6 +477,13 @@ def synth_deg(g):
 if __name__ == '__main__':
     torch.manual_seed(0)
     real_rand_like = torch.rand_like
+    if len(sys.argv) > 1 and sys.argv[1] == 'dropout':
+        try:
+            gen_loss('ragged', [0, 7, 47, 12, 1, 20], tag='_dp', dp=0.1)
+            gen_loss('polblogs1', [100], tag='_dp', dp=0.1)
+        finally:
+            torch.rand_like = real_rand_like
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'trajbig':
         try:
             gen_traj_big('polblogs1')
@@ -468,6 +500,8 @@ if __name__ == '__main__':
         gen_loss('toy', [6, 4], tag='_mid')
         gen_loss('ragged', [0, 7, 47, 12, 1, 20])
         gen_loss('polblogs1', [100])
+        gen_loss('ragged', [0, 7, 47, 12, 1, 20], tag='_dp', dp=0.1)      # README.md:49,79: --dp_rate 0.1
+        gen_loss('polblogs1', [100], tag='_dp', dp=0.1)
         gen_traj('toy')
         gen_traj('ragged')
     finally:

@@ -647,3 +647,129 @@ def test_sampling_and_training_follow_the_callers_stream():
     for a, b_ in zip(g0, g1):
         assert float((a - b_).abs().max()) / scale < 2e-4
     assert float((g0[0] - g0[1]).abs().max()) / scale < 2e-4
+
+
+# ---- dropout (--dp_rate 0.1 of the reference's training templates, README.md:49,79) -----------------------------
+@pytest.mark.parametrize('name,case', [('loss_ragged_dp', 'ragged'), ('loss_polblogs1_dp', 'polblogs1')])
+@pytest.mark.parametrize('form', ['fused', 'ops'])
+def test_dropout_loss_and_gradients_vs_reference_golden(name, case, form):
+    """Training-mode dropout on both GRU-side activations (layers.py:357,361) with SUPPLIED keep-masks: the golden
+    values come from the reference run with its nn.Dropout patched to the same masks; gradients against torch autograd
+    through the oracle with the same masks."""
+    g = H.golden(name + '.npz')
+    builder, T, wseed, useed = cases.CASES[case]
+    graphs = builder()
+    rng = np.random.default_rng(useed + 1)
+    Nn = sum(x['n'] for x in graphs)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in graphs)
+    us = [cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2), cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)]
+    masks = cases.dropout_masks(useed, Nn, 0.1)
+    t, pt = torch.from_numpy(g['t']), torch.from_numpy(g['pt'])
+    params = orc.random_tgnn_params(wseed)
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    o = orc.EdgeOracle(po, T, int(g['max_degree']))
+    o.dropout = orc.mask_dropout(masks, 0.1)
+    ob = orc.make_batch(graphs, degree_dtype=torch.int64)
+    ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+    ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+    orc.elbo_bpd(o.loss(ob, t, pt, orc.UniformTape(us), training=True), ob.num_entries).backward()
+
+    import edgehip
+    args = H.make_args(T, int(g['max_degree']))
+    args.dp_rate = 0.1
+    model = edgehip.get_model(args, None)
+    model._denoise_fn.load_state_dict(params, strict=True)
+    model = model.to('cuda').train()
+    model.train_form = form
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    want = {}
+    dm = torch.stack(masks).cuda().contiguous()
+    nv = model.log_prob(b, t, pt, us[1].cuda(), us[3].cuda(), want, dropout_masks=dm)
+    np.testing.assert_allclose(nv.detach().cpu().numpy(), g['neg_vb'], rtol=1e-4, atol=1e-12)
+    assert H.rel_err(want['logits'], g['logits']) < 1e-4
+    # the dropout really acts: the dp 0 golden of the same case differs
+    g0 = H.golden(name[:-3] + '.npz')
+    assert H.rel_err(want['logits'], g0['logits']) > 1e-3
+    (-nv.sum() / (np.log(2) * b.num_entries)).backward()
+    named = dict(model._denoise_fn.named_parameters())
+    gmax = max(float(r.grad.abs().max()) for r in po.values() if r.grad is not None)
+    checked = 0
+    for k, ref in po.items():
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            continue
+        scale = max(float(ref.grad.abs().max()), 1e-6 * gmax)
+        err = float((named[k].grad.detach().cpu().double() - ref.grad.double()).abs().max()) / scale
+        assert err < GRAD_TOL, (k, err)
+        checked += 1
+    assert checked >= 80
+    # eval mode: the dropout is off (torch.nn.Dropout follows the module mode) and the dp 0 golden comes back
+    model.eval()
+    with torch.no_grad():
+        nv0 = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda())
+    np.testing.assert_allclose(nv0.cpu().numpy(), g0['neg_vb'], rtol=1e-4, atol=1e-12)
+    # train mode under no_grad keeps the dropout on, like the reference
+    model.train()
+    with torch.no_grad():
+        nv1 = model.log_prob(H.graph_batch(graphs, degree_dtype=np.int64), t, pt, us[1].cuda(), us[3].cuda(), dropout_masks=dm)
+    np.testing.assert_allclose(nv1.cpu().numpy(), g['neg_vb'], rtol=1e-4, atol=1e-12)
+
+
+def test_generated_dropout_masks_are_bernoulli_scaled_reproducible_and_shard_invariant():
+    """Without supplied masks the keep decisions come from Philox keyed (seed; graph global id, node, channel, slot)."""
+    import edgehip
+    from edgehip import capi
+    n = [300, 500, 200]
+    b = edgehip.GraphBatch(n, degree=[np.zeros(k) for k in n], device='cuda', gid_base=4)
+    Nn = sum(n)
+    x = torch.randn(Nn, 64, device='cuda')
+    dp = capi.Dropout()
+    dp.p, dp.seed = 0.1, 12345
+
+    def run(batch, xin, slot, seed=12345):
+        dp.seed = seed
+        y = torch.empty_like(xin)
+        capi.check(capi.lib.edgehip_dropout_fwd(C.byref(batch.layout), xin.data_ptr(), C.byref(dp), slot, y.data_ptr(),
+                                                capi.stream_ptr()), 'dropout')
+        return y
+    y = run(b, x, 3)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.9) < 0.01
+    assert torch.equal(y[kept], (x * np.float32(1.0 / np.float32(0.9)))[kept])
+    assert torch.equal(run(b, x, 3), y)                                   # reproducible
+    assert not torch.equal(run(b, x, 4) != 0, kept)                       # another slot, another mask
+    assert not torch.equal(run(b, x, 3, seed=7) != 0, kept)               # another seed
+    # graph 1 alone, carrying its global id, draws the same mask
+    b1 = edgehip.GraphBatch([500], degree=[np.zeros(500)], device='cuda', gid_base=5)
+    assert torch.equal(run(b1, x[300:800].contiguous(), 3), y[300:800])
+    # p = 0 is the identity; p outside [0, 1) is refused
+    dp.p = 0.0
+    assert torch.equal(run(b, x, 0), x)
+    dp.p = 1.0
+    assert capi.lib.edgehip_dropout_fwd(C.byref(b.layout), x.data_ptr(), C.byref(dp), 0, x.data_ptr(), None) == capi.ERR_ARG
+
+
+def test_training_with_generated_dropout_runs_and_differs_between_steps():
+    import edgehip
+    graphs = cases.ragged_graphs(7)
+    T, dmax = 48, cases.max_degree_of(graphs)
+    args = H.make_args(T, dmax)
+    args.dp_rate = 0.1
+    model = edgehip.get_model(args, None)
+    model._denoise_fn.load_state_dict(orc.random_tgnn_params(3), strict=True)
+    model = model.to('cuda').train()
+    b = H.graph_batch(graphs, degree_dtype=np.int64)
+    P = b.num_pairs
+    rng = np.random.default_rng(2)
+    u1, u3 = cases.uniforms(rng, P, 2).cuda(), cases.uniforms(rng, P, 2).cuda()
+    t = torch.tensor([5, 9, 3, 20, 1, 13])
+    pt = torch.full((6,), 1.0 / T)
+    model.rng_seed = 5
+    a = model.log_prob(b, t, pt, u1, u3)
+    c = model.log_prob(b, t, pt, u1, u3)              # next seed -> other masks
+    model.rng_seed = 5
+    a2 = model.log_prob(b, t, pt, u1, u3)
+    # (per-graph CE sums use float atomics: equal to rounding, not bit for bit)
+    assert torch.allclose(a, a2, rtol=1e-5, atol=0) and not torch.allclose(a, c, rtol=1e-4, atol=0)
+    opt = edgehip.make_optimizer(model)
+    l0 = float(edgehip.train_step(model, b, opt, clip_value=1.0, state={}))
+    assert np.isfinite(l0)
