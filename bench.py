@@ -1,17 +1,23 @@
 """bench.py - sampled graphs/sec of the degree-guided reverse process, polblogs shape, T = 512.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 ...                      (starts 8 ranks itself when not under a launcher)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: model.sample() of `--graphs` (default 64)
-polblogs-shaped graphs through all 512 reverse steps, state resident in HBM, ending with the edge
-lists on the device.  Every rank samples its own `--graphs` graphs (weak scaling, no data-path
-collective; graph global ids key the RNG so results do not depend on the sharding).
+A "step" is one pass of the hot path over one batch: model.sample() of the rank's graphs through all 512 reverse
+steps, state resident in HBM, ending with the edge lists on the device.  Graphs of a sampling run are independent:
+they are sharded over the ranks by global graph id with no data-path collective (the RNG is keyed by that id, so
+the sampled graphs do not depend on the sharding).
+  weak scaling (default):   every rank samples `--graphs` (64) graphs per step;
+  strong scaling:           `--total-graphs 64` = BASELINE config 3, the 64 generations split 64/N per rank.
+Under N > 1 the weak run also times the strong configuration and reports it as `strong_scaling`.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,20 +26,65 @@ for p in (ROOT, os.path.join(ROOT, 'graph-generation-edge_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 T_STEPS = 512
 HEADS = [8, 8, 8, 8, 1]
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, Peak FP32 (matrix)
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md, BF16 dense
 BF16_PRODUCTS_PER_FP32 = 6        # csrc/gemm.h: exact 3-way bf16 split of both operands, six products kept
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md, HBM3E peak
-SURVEY_GB_PER_GRAPH = 40.7        # algorithmic HBM bytes per sampled polblogs graph
+SURVEY_GB_PER_GRAPH = 40.7        # bytes of the UNFOLDED formulation per sampled polblogs graph
+PMC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')     # newest first
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--graphs', type=int, default=64, help='weak scaling: graphs sampled per GPU per step (num_generation)')
+    ap.add_argument('--total-graphs', type=int, default=0,
+                    help='strong scaling: graphs per step over ALL ranks (64 = BASELINE config 3); overrides --graphs')
+    ap.add_argument('--parts', type=int, default=0,
+                    help='sub-batches (HIP streams) per sampling pass; 0 = the sampler default (3 for 64 graphs)')
+    ap.add_argument('--train-steps', type=int, default=10, help='secondary metric: timed training steps (0 = skip)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='NOT a measurement: all ranks share cuda:0 and talk over gloo, to exercise the multi-rank code '
+                         'paths (launcher, sharding, strong-scaling leg, data-parallel training) on a one-GPU box')
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script as CHILD processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relay rank 0's JSON line.  This process has
+    not touched the GPU and never does (no exec from a process that initialised it)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                       # this exact child
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def make_model(n, edges, device, T=T_STEPS):
     from types import SimpleNamespace
+    import torch
     import edgehip
     from edgehip import synth
     d = synth.degrees(n, edges)
@@ -49,42 +100,46 @@ def make_model(n, edges, device, T=T_STEPS):
     return model, d
 
 
-def kernel_work(name, Nn, launches_per_pass):
-    """Algorithmic flops / bytes of ONE launch of a kernel class at this workload (DESIGN.md 'Kernels').
-    Per-layer kernels run once per layer with different head counts; their per-launch figure is the
-    average over the 5 layers.  Flops are those of the FOLDED formulation the library executes
-    (keys / values never formed), i.e. the lower, honest count - not the reference's 2.6 MFLOP/node."""
-    hs = HEADS
-    if name == 'layer':          # fused layer: q~ = h Mcat, conv = [z|h] Ocat, GRU (6 x 64x64), ctx 64->256
-        fl = np.mean([2.0 * Nn * (64 * 64 * h + (64 * h + 64) * 64 + 6 * 64 * 64 + 64 * 256) for h in hs])
-        # HBM: read h row + bit row (~160 B) , write h' row + per-tile context sums; q~/z stay in LDS,
-        # neighbour rows and weights are L2-resident re-reads
-        by = Nn * (256 + 160 + 256) + (Nn / 32) * 1024
-    else:                        # heavy-row attention etc. are data-dependent: no fixed per-launch figure
-        return None
+def layer_work(rows):
+    """Algorithmic flops / HBM bytes of ONE launch of the fused layer kernel over `rows` node rows (DESIGN.md
+    'Kernels'), averaged over the 5 layers.  Flops are those of the FOLDED formulation the library executes (keys /
+    values never formed): q~ = h Mcat, conv = [z|h] Ocat, GRU (6 x 64x64), ctx 64->256."""
+    import numpy as np
+    fl = np.mean([2.0 * rows * (64 * 64 * h + (64 * h + 64) * 64 + 6 * 64 * 64 + 64 * 256) for h in HEADS])
+    # HBM: read h row + bit row (~160 B), write h' row + per-tile context sums; q~/z stay in LDS, neighbour rows
+    # and weights are L2-resident re-reads
+    by = rows * (256 + 160 + 256) + (rows / 32) * 1024
     return fl, by
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run
-    inside this process): profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py from two
-    `rocprofv3 --pmc` runs of this same script; None when the file or the kernel is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    pref = {'layer': 'k_layer'}.get(kernel_class)
-    if pref is None or not os.path.exists(path):
-        return None, None
-    with open(path) as fh:
-        kk = json.load(fh)['kernels']
-    sel = [v for k, v in kk.items() if k.startswith(pref)]
-    if not sel:
-        return None, None
-    n = sum(v['launches'] for v in sel)
-    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, 'profiles/r01_pmc_traffic.json'
+def train_flops(Nn, directed_edges, A):
+    """Algorithmic flops of one training step (forward of the UNFOLDED network as the reference runs it, layers.py:
+    315-383, + backward = 2x forward: dX and dW products)."""
+    node = 2 * 192 * 64 + 2 * (256 * 128 + 128 * 128 + 128 * 128)
+    for h in HEADS:
+        node += 3 * 2 * 128 * 64 * h + 2 * 128 * 64 + 2 * 2 * 64 * 192 + 2 * 128 * 256 + 2 * 256 * 64
+    edge = sum(256 * h for h in HEADS)                # per directed edge and head: score (2*64) + weighted sum (2*64)
+    pair = 2 * (128 * 128 + 128 * 64 + 64 * 2)
+    return 3.0 * (Nn * node + directed_edges * edge + A * pair)
+
+
+def pmc_traffic():
+    """Per-kernel HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
+    profiles/r0X_pmc_traffic.json, made by tools/pmc_traffic.py from two `rocprofv3 --pmc` runs (FETCH_SIZE,
+    WRITE_SIZE) of `bench.py --parts 1 --steps 1 --warmup 0`; None when absent."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh)['kernels'], 'profiles/' + name
+    return None, None
 
 
 def cpu_baseline(model, n, edges, deg, budget_s=20.0):
     """Oracle (dense-semantics torch CPU restatement of the reference) timed on this host: reverse steps
     of ONE polblogs-shaped graph at t spread over the trajectory; graphs/s = 1 / (mean step s x 512)."""
+    import numpy as np
+    import torch
     from oracle import edge_oracle as orc
     params = {k[len('_denoise_fn.'):]: v.detach().cpu() for k, v in model.state_dict().items()
               if k.startswith('_denoise_fn.')}
@@ -116,27 +171,28 @@ def cpu_baseline(model, n, edges, deg, budget_s=20.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--graphs', type=int, default=64, help='graphs sampled per GPU per step (num_generation)')
-    ap.add_argument('--parts', type=int, default=0,
-                    help='sub-batches (HIP streams) per sampling pass; 0 = the sampler default (3 for 64 graphs)')
-    ap.add_argument('--train-steps', type=int, default=10, help='secondary metric: timed training steps (0 = skip)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    a = ap.parse_args()
+    a = parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
 
+    import numpy as np
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = world > 1
+    if a.rehearse_on_one_gpu:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(75, exit=True)      # a rehearsal that hangs says where
     if dist:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        td.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if a.rehearse_on_one_gpu:
+            td.init_process_group('gloo')
+        else:
+            td.init_process_group('nccl', device_id=torch.device('cuda', local))
     device = f'cuda:{local}'
     torch.cuda.set_device(local)
 
@@ -144,61 +200,73 @@ def main():
     from edgehip import capi, synth
     n, edges = synth.polblogs_like(0)
     model, deg = make_model(n, edges, device)
-    B = a.graphs
-    gid_base, count = edgehip.shard.shard_generations(world * B, rank, world)     # weak scaling: B per rank
-    assert count == B
-    batch = edgehip.GraphBatch([n] * B, degree=[deg] * B, device=device, gid_base=gid_base)
-
-    parts = a.parts if a.parts > 0 else model.default_parts(B)
-
-    def one_pass(i, parts=parts):
-        return model.sample_batch(batch, seed=1000 + i, parts=parts)
 
     def barrier():
         if dist:
             td.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one_pass(-1 - i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = one_pass(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = edgehip.shard.max_over_ranks(elapsed, device)
-    edges_out = int(out._slice_dict['edge_index'][-1].item())
-    value = world * B * a.steps / elapsed
+    def timed(total, steps, warmup, parts_arg, seed0):
+        """`steps` passes of `total` graphs over all ranks -> (elapsed max over ranks, this rank's batch, parts, last out)"""
+        gid_base, count = edgehip.shard.shard_generations(total, rank, world)
+        batch = edgehip.GraphBatch([n] * count, degree=[deg] * count, device=device, gid_base=gid_base)
+        parts = parts_arg if parts_arg > 0 else model.default_parts(count)
+        out = None
+        for i in range(warmup):
+            out = model.sample_batch(batch, seed=seed0 - 1 - i, parts=parts) if count else None
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = model.sample_batch(batch, seed=seed0 + i, parts=parts) if count else None
+        barrier()
+        el = edgehip.shard.max_over_ranks(time.perf_counter() - t0, device)
+        return el, batch, parts, out
+
+    strong = a.total_graphs > 0
+    total = a.total_graphs if strong else world * a.graphs
+    elapsed, batch, parts, out = timed(total, a.steps, a.warmup, a.parts, 1000)
+    B = batch.num_graphs
+    edges_out = int(out._slice_dict['edge_index'][-1].item()) if out is not None else 0
+    value = total * a.steps / elapsed
 
     res = {'metric': 'sampled graphs/sec, polblogs 512 steps', 'value': value, 'unit': 'graphs/s', 'n_gpus': world,
            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'dtype_note': 'fp32 state, weights, accumulation and results; the dense products run on the bf16 matrix pipe as '
                          'six products of exact three-way bf16 splits of both fp32 operands (logit error vs the reference '
                          'unchanged: 5e-7, DESIGN.md 5)',
            'config': {'workload': 'polblogs-shaped synthetic graph (n 1222, E 16714, d_max ~351; the pickle is never '
                                   'loaded), T=512 linear schedule, TGNN_degree_guided dim 64 heads 8/8/8/8/1 random '
-                                  f'init, empirical d0, {B} generations per GPU per step', 'graphs_per_gpu': B,
-                      'diffusion_steps': T_STEPS, 'nodes_per_graph': n, 'sharding': f'sample-parallel x{world}',
-                      'streams_per_gpu': parts},
-           'mean_edges_per_sampled_graph': edges_out / B,
-           'path_hbm': {'algorithmic_GB_per_graph': SURVEY_GB_PER_GRAPH,
-                        'achieved_GBps_per_gpu': value / world * SURVEY_GB_PER_GRAPH,
-                        'frac_of_hbm_peak': value / world * SURVEY_GB_PER_GRAPH / HBM_PEAK_GBPS}}
+                                  f'init, empirical d0, {total} generations per step over {world} GPU(s)',
+                      'graphs_per_gpu': B, 'total_graphs_per_step': total, 'diffusion_steps': T_STEPS,
+                      'nodes_per_graph': n, 'sharding': f'sample-parallel x{world}', 'streams_per_gpu': parts},
+           'mean_edges_per_sampled_graph': edges_out / max(B, 1)}
+    if a.rehearse_on_one_gpu:
+        res['rehearsal'] = 'all ranks on cuda:0 over gloo: exercises the multi-rank code paths, the numbers mean nothing'
 
-    if not a.no_roofline:
-        # one more pass of the same workload with HIP events around every launch (on the launch stream).  This pass
-        # runs the batch as ONE block of graphs on one stream: in the timed passes blocks of graphs overlap on
-        # several streams, and the duration of a launch that shares the chip with another stream's launches is
-        # not a property of the kernel (`python bench.py --parts 1` times that configuration end to end)
+    if dist and not strong:
+        # BASELINE config 3 as written: the 64 generations of ONE sampling run split over the ranks (64/N each)
+        sel, sb, sparts, _ = timed(64, max(1, min(a.steps, 3)), 1, a.parts, 5000)
+        ssteps = max(1, min(a.steps, 3))
+        res['strong_scaling'] = {'total_graphs_per_step': 64, 'graphs_per_gpu': sb.num_graphs, 'streams_per_gpu': sparts,
+                                 'value': 64 * ssteps / sel, 'unit': 'graphs/s', 'steps': ssteps,
+                                 'ms_per_step': 1e3 * sel / ssteps}
+
+    if not a.no_roofline and B > 0 and rank == 0:
+        # One more pass of the same workload with HIP events around every launch (on the launch stream) and the
+        # per-step work counters.  It runs the batch as ONE block of graphs on one stream: in the timed passes blocks
+        # of graphs overlap on several streams, and the duration of a launch that shares the chip with another
+        # stream's launches is not a property of the kernel (`python bench.py --parts 1` times that end to end).
         import ctypes
         rows_done = ctypes.c_ulonglong(0)
+        stats = torch.zeros((T_STEPS, 8), dtype=torch.int64, device=device)
         torch.cuda.synchronize()
-        capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         capi.lib.edgehip_prof_enable(1)
-        one_pass(10 ** 6, parts=1)
+        capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
+        t0 = time.perf_counter()
+        model.sample_batch(batch, seed=1000 + a.steps - 1, parts=1, step_stats=stats)    # the last timed pass again
         torch.cuda.synchronize()
+        one_stream_s = time.perf_counter() - t0
         capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
         prof = capi.prof_collect()
         capi.lib.edgehip_prof_enable(0)
@@ -206,37 +274,67 @@ def main():
         kern = {k: {'ms': round(v[0], 3), 'launches': v[1], 'avg_us': round(1e3 * v[0] / v[1], 3),
                     'share': round(v[0] / tot, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         dom = next(iter(kern))
-        # rows per launch that were really processed: graphs without active pairs are skipped by the kernels
-        Nn = rows_done.value / kern['layer']['launches'] if dom == 'layer' else n * B
-        w = kernel_work(dom, Nn, kern[dom]['launches'])
         roof = None
-        if w is not None:
-            fl, by = w
+        if dom == 'layer':
+            rows = rows_done.value / kern['layer']['launches']      # rows per launch really processed
+            fl, by = layer_work(rows)
             dur = kern[dom]['avg_us'] * 1e-6
-            if fl > 0 and fl / by > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
-                ach = fl / dur / 1e12
-                roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None}
-            else:
-                ach = by / dur / 1e9
-                roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBPS, 'traffic': None}
-            if roof['bound'] == 'mfma':
-                # the fp32 products are EXECUTED as six bf16 MFMA products (same fp32 result to rounding): the
-                # figure above prices the algorithmic fp32 flops against the fp32 matrix peak, this one the executed
-                # bf16 flops against the bf16 peak
-                ex = BF16_PRODUCTS_PER_FP32 * fl / dur / 1e12
-                roof['executed'] = {'instruction': 'v_mfma_f32_32x32x16_bf16, 6 products per fp32 product',
-                                    'achieved': ex, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                    'frac': ex / MFMA_BF16_PEAK_TFLOPS}
-            roof['traffic'], roof['traffic_source'] = pmc_traffic(dom)
-            roof['measured'] = 'one extra pass, whole batch on one stream (kernel alone on the chip)'
-            roof['avg_launch_us'] = kern[dom]['avg_us']
-            roof['rows_per_launch'] = Nn
-            roof['algorithmic_bytes_per_launch'] = by
-            roof['algorithmic_flops_per_launch'] = fl
+            ach = fl / dur / 1e12
+            ex = BF16_PRODUCTS_PER_FP32 * ach
+            roof = {'kernel': 'k_layer<h> (fused GNN layer)', 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                    # the fp32 products are EXECUTED as six bf16 MFMA products: the figure above prices the algorithmic
+                    # fp32 flops against the fp32 matrix peak, this one the executed bf16 flops against the bf16 peak
+                    'executed': {'instruction': 'v_mfma_f32_32x32x16_bf16, 6 products per fp32 product', 'achieved': ex,
+                                 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / MFMA_BF16_PEAK_TFLOPS},
+                    'measured': 'one extra pass, whole batch on one stream (kernel alone on the chip)',
+                    'avg_launch_us': kern[dom]['avg_us'], 'rows_per_launch': rows,
+                    'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
+                    'hbm_frac_of_this_kernel': by / dur / 1e9 / HBM_PEAK_GBPS}
         res['roofline'] = roof
         res['kernels'] = kern
+
+        # ---- the work of the timed trajectory (it depends on how fast THIS network adds edges)
+        st = stats.cpu().numpy()[::-1]              # row 0 = first reverse step (t = T-1)
+        nodes_all = n * B
+        idx = list(range(0, T_STEPS, 32)) + [T_STEPS - 1]
+        res['trajectory'] = {
+            'note': 'per reverse step, summed over the batch; every 32nd step listed (first = t 511). idle graph = '
+                    'fewer than 2 active nodes (skipped); live rows = node rows left after isolated-class compaction',
+            't': [T_STEPS - 1 - i for i in idx],
+            'edges_E_t': [int(st[i, 6] // 2) for i in idx],
+            'active_nodes_K': [int(st[i, 0]) for i in idx],
+            'active_pairs_A': [int(st[i, 1]) for i in idx],
+            'non_idle_graphs': [int(st[i, 2]) for i in idx],
+            'live_rows': [int(st[i, 3]) for i in idx],
+            'heavy_rows': [int(st[i, 4]) for i in idx],
+            'total_pair_decisions': int(st[:, 1].sum()),
+            'idle_graph_step_fraction': float(1.0 - st[:, 2].sum() / (B * T_STEPS)),
+            'live_row_fraction_of_all_rows': float(st[:, 3].sum() / (nodes_all * T_STEPS)),
+            'live_row_fraction_of_non_idle_rows': float(st[:, 3].sum() / max(st[:, 7].sum(), 1))}
+
+        # ---- achieved HBM GB/s of the whole path, from the counters
+        kk, src = pmc_traffic()
+        hbm = {'unfolded_formulation_equivalent': {
+            'note': 'NOT a measurement: graphs/s x the 40.7 GB per graph the UNFOLDED reference formulation would move '
+                    '(SURVEY.md 8d); the kernels here never move those bytes',
+            'GBps_per_gpu': value / world * SURVEY_GB_PER_GRAPH}}
+        if kk is not None and B == 64:
+            per_pass = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in kk.values())
+            hbm.update({'source': src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at --parts 1, '
+                                        'gfx950 corrections of MI355X_MICROARCH.md)',
+                        'counter_bytes_per_pass': per_pass, 'GB_per_graph': per_pass / 64 / 1e9,
+                        'achieved_GBps': per_pass / (elapsed / a.steps) / 1e9,
+                        'frac_of_hbm_peak': per_pass / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBPS})
+            if roof is not None:
+                sel = [v for k, v in kk.items() if k.startswith('k_layer')]
+                if sel:
+                    nl = sum(v['launches'] for v in sel)
+                    roof['traffic'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / nl
+                    roof['traffic_source'] = src
+        res['path_hbm'] = hbm
+        res['one_stream_pass_ms'] = 1e3 * one_stream_s
+
     if a.train_steps > 0:
         # secondary metric: training steps/sec = elbo_bpd fwd + bwd + clip + Adam on the
         # reference's polblogs batch (4 copies of the graph with independent t, README.md:70), data-parallel
@@ -260,6 +358,21 @@ def main():
         res['train'] = {'metric': 'training steps/sec, polblogs batch 4 per GPU (fwd + bwd + clip + Adam)',
                         'value': a.train_steps / tel, 'unit': 'steps/s', 'ms_per_step': 1e3 * tel / a.train_steps,
                         'graphs_per_step': TB * world, 'last_bpd': float(bpd)}
+        # roofline of the step: algorithmic flops of fwd + bwd at the mean (E_t, A) of 16 more (untimed) steps with
+        # the same t distribution, against the fp32 matrix peak (the products are fp32 MFMA here)
+        As, Es = [], []
+        for _ in range(16):
+            edgehip.train_step(tmodel, tb, opt, clip_value=1.0, state=tstate)
+            As.append(int(tb.active_row.numel()))
+            Es.append(tb._state['deg_t'][:tb.num_nodes].sum())
+        torch.cuda.synchronize()
+        dirE = float(np.mean([int(e) for e in Es]))
+        fl = train_flops(tb.num_nodes, dirE, float(np.mean(As)))
+        ach = fl / (tel / a.train_steps) / 1e12
+        res['train']['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': ach / MFMA_F32_PEAK_TFLOPS, 'algorithmic_flops_per_step': fl,
+                                    'mean_active_pairs': float(np.mean(As)), 'mean_directed_edges': dirE,
+                                    'note': 'whole step (~240 launches, latency-bound at 4 888 node rows), not one kernel'}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(model, n, edges, deg)
     if rank == 0:

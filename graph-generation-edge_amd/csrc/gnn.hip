@@ -1824,6 +1824,49 @@ extern "C" int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_p
 }
 
 // --------------------------------------------------------------------------------------------
+// measurement hook: what the LAST edgehip_sample_step on this workspace worked on (bench.py prints the profile of
+// the timed trajectory with it).  out[8] int64 on the device: active nodes K, active pairs A, graphs with >= 2
+// active nodes (the others were skipped), live node rows after the isolated-class compaction, heavy rows, long
+// rows, sum of degrees of the state the step started from (= 2 E_t), nodes in the non-idle graphs.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step_stats(edgehip_layout L, const int32_t* __restrict__ kptr,
+                                                    const int32_t* __restrict__ ccount, const int32_t* __restrict__ heavy,
+                                                    const int32_t* __restrict__ deg, const edgehip_counts* __restrict__ counts,
+                                                    long long* __restrict__ out) {
+    __shared__ long long red[3][256];
+    const int tid = threadIdx.x;
+    long long act = 0, live = 0, dsum = 0, nodes = 0;
+    for (int g = tid; g < L.num_graphs; g += 256)
+        if (kptr[g + 1] - kptr[g] >= 2) { act += 1; live += ccount[g]; nodes += L.node_ptr[g + 1] - L.node_ptr[g]; }
+    for (int i = tid; i < L.num_nodes; i += 256) dsum += deg[i];
+    red[0][tid] = act; red[1][tid] = live; red[2][tid] = dsum;
+    __shared__ long long rn[256];
+    rn[tid] = nodes;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) { red[0][tid] += red[0][tid + d]; red[1][tid] += red[1][tid + d]; red[2][tid] += red[2][tid + d]; rn[tid] += rn[tid + d]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = counts->k_total; out[1] = counts->a_total; out[2] = red[0][0]; out[3] = red[1][0];
+        out[4] = red[0][0] ? heavy[0] : 0; out[5] = red[0][0] ? heavy[1] : 0; out[6] = red[2][0]; out[7] = rn[0];
+    }
+}
+
+extern "C" int edgehip_prof_step_stats(const edgehip_layout* L, const edgehip_gnn_params* P, void* ws, size_t ws_bytes,
+                                       const edgehip_counts* counts, int64_t* out_dev, void* stream) {
+    int rc = eh_check_params(P);
+    if (rc != EDGEHIP_OK) return rc;
+    EH_CHECK_ARG(L && ws && counts && out_dev);
+    eh_ws w = eh_carve(L, P, ws);
+    if (ws_bytes < w.bytes) return EDGEHIP_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k_step_stats, dim3(1), dim3(256), 0, eh_stream(stream), *L, w.kptr, w.ccount, w.heavy_count, w.deg, counts,
+                       reinterpret_cast<long long*>(out_dev));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
+// --------------------------------------------------------------------------------------------
 // The same loss for callers that cannot allocate (HIP graph capture, tight serving loops): the per-tile
 // partial sums live in a file-scope device array instead of a caller buffer.  Every GPU holds its own copy
 // of the array at its own address; host code must use the address hipGetSymbolAddress returns for the

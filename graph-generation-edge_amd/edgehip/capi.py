@@ -79,6 +79,7 @@ EXPORTS = {
                              vp, vp, C.c_int64, vp],
     'edgehip_edge_ce_loss_static': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, vp],
+    'edgehip_prof_step_stats': [C.POINTER(Layout), C.POINTER(GnnParams), vp, C.c_size_t, vp, vp, vp],
     'edgehip_sample_step': [C.POINTER(Layout), C.POINTER(GnnParams), vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp,
                             C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
     'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],

@@ -477,7 +477,7 @@ class BinomialDiffusionActive(nn.Module):
 
     @_on_batch_device
     @torch.no_grad()
-    def sample_batch(self, batch, seed=None, parts=None):
+    def sample_batch(self, batch, seed=None, parts=None, step_stats=None):
         """T fused reverse steps of a prepared batch (no host sync), then the edge-list epilogue.
         parts > 1: contiguous blocks of graphs run on separate HIP streams, their steps issued round-robin.
         Graphs do not interact and the uniforms are keyed by the global graph id, so the result is the same
@@ -490,6 +490,11 @@ class BinomialDiffusionActive(nn.Module):
         tabs = self._tables(dev, nmax)
         rng = capi.Rng(self._next_seed() if seed is None else seed)
         parts = self.default_parts(batch.num_graphs) if parts is None else max(1, min(int(parts), max(batch.num_graphs, 1)))
+        if step_stats is not None:
+            # measurement: int64 [T, 8] device tensor, row t <- edgehip_prof_step_stats after step t (no host sync)
+            assert step_stats.dtype == torch.int64 and tuple(step_stats.shape) == (self.num_timesteps, 8) and \
+                step_stats.is_contiguous() and step_stats.device == dev
+            parts = 1
         step = capi.lib.edgehip_sample_step
         post, lut, tn = tabs['post'].data_ptr(), capi.ptr(tabs['lut']), tabs['nmax']
         fptr, rref, pref = folded.data_ptr(), byref(rng), byref(P)
@@ -521,6 +526,9 @@ class BinomialDiffusionActive(nn.Module):
                 rc = step(Lr, pref, fptr, adj, d0, t, post, tn, None, None, rref, lut, counts, ws, wsn, s)
                 if rc:
                     capi.check(rc, f'sample_step t={t}')
+                if step_stats is not None:
+                    capi.check(capi.lib.edgehip_prof_step_stats(Lr, pref, ws, wsn, counts, step_stats.data_ptr() + 64 * t, s),
+                               'prof_step_stats')
         for st in streams[1:]:
             streams[0].wait_stream(st)
         return self._finish_sample(batch)
@@ -725,8 +733,9 @@ class BinomialDiffusionActive(nn.Module):
                 capi.ptr(logits) if A and logits is not None else None, A, s), 'edge_ce_loss')
         if training:     # active.py:250-254; under data parallelism every replica applies every rank's pairs
             from . import shard
-            t_all = shard.all_gather_cat(t)
-            Lt2 = shard.all_gather_cat(kl.detach()).pow(2)
+            # one all-gather carries the local pair count and every rank's (t, kl)
+            batch._global_entries, t_all, kl_all = shard.gather_step_scalars(batch.num_pairs, t, kl)
+            Lt2 = kl_all.pow(2)
             prev = self.Lt_history.gather(dim=0, index=t_all)
             self.Lt_history.scatter_(dim=0, index=t_all, src=(0.1 * Lt2 + 0.9 * prev))
             self.Lt_count.scatter_add_(dim=0, index=t_all, src=torch.ones_like(Lt2))

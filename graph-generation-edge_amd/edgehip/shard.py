@@ -26,7 +26,7 @@ def max_over_ranks(value, device='cpu'):
     import torch.distributed as td
     if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device='cpu' if td.get_backend() == 'gloo' else device)
     td.all_reduce(t, op=td.ReduceOp.MAX)
     return float(t.item())
 
@@ -62,7 +62,7 @@ def sum_over_ranks(value, device='cpu'):
     td = _dist()
     if td is None:
         return value
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if td.get_backend() == 'gloo' else device)
     td.all_reduce(t, op=td.ReduceOp.SUM)
     return float(t.item())
 
@@ -73,9 +73,41 @@ def sum_over_ranks_device(value, device):
     td = _dist()
     if td is None:
         return value
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if td.get_backend() == 'gloo' else device)
     td.all_reduce(t, op=td.ReduceOp.SUM)
-    return t[0].to(torch.float32)
+    return t[0].to(torch.float32).to(device)
+
+
+def _host_staged(x):
+    """gloo moves host memory only: under it a device tensor is staged through the host (CPU rehearsals of the
+    multi-rank paths on a one-GPU box); RCCL takes device tensors as they are."""
+    import torch.distributed as td
+    return x.is_cuda and td.get_backend() == 'gloo'
+
+
+def gather_step_scalars(num_entries, t, kl):
+    """ONE all-gather per training step for everything the replicas exchange besides the gradients: the local pair
+    count (elbo_bpd normalises by the GLOBAL one, diffusion/loss.py:10-12) and every rank's (t, kl) for the importance
+    history (diffusion_binomial_active.py:250-254).  Returns (global pair count as a 0-d fp32 tensor or the python
+    number without a group, t of all ranks int64, kl of all ranks fp32), equal lengths per rank assumed."""
+    td = _dist()
+    if td is None:
+        return num_entries, t, kl
+    B = t.numel()
+    # fp64 payload: t < 2^53 and pair counts up to 2^53 stay exact
+    msg = torch.empty(1 + 2 * B, dtype=torch.float64, device=t.device)
+    msg[0] = float(num_entries)
+    msg[1:1 + B] = t.to(torch.float64)
+    msg[1 + B:] = kl.detach().to(torch.float64)
+    staged = _host_staged(msg)
+    src = msg.cpu() if staged else msg
+    outs = [torch.empty_like(src) for _ in range(td.get_world_size())]
+    td.all_gather(outs, src)
+    allm = torch.stack(outs)
+    if staged:
+        allm = allm.to(t.device)
+    return allm[:, 0].sum().to(torch.float32), allm[:, 1:1 + B].reshape(-1).to(torch.int64), \
+        allm[:, 1 + B:].reshape(-1).to(torch.float32)
 
 
 def all_gather_cat(x):
@@ -85,9 +117,12 @@ def all_gather_cat(x):
     td = _dist()
     if td is None:
         return x
-    outs = [torch.empty_like(x) for _ in range(td.get_world_size())]
-    td.all_gather(outs, x.contiguous())
-    return torch.cat(outs)
+    staged = _host_staged(x)
+    src = x.cpu() if staged else x.contiguous()
+    outs = [torch.empty_like(src) for _ in range(td.get_world_size())]
+    td.all_gather(outs, src)
+    out = torch.cat(outs)
+    return out.to(x.device) if staged else out
 
 
 def allreduce_gradients(params, bucket=None):
@@ -111,7 +146,12 @@ def allreduce_gradients(params, bucket=None):
         else:
             bucket[o:o + k].copy_(p.grad.reshape(-1))
         o += k
-    td.all_reduce(bucket, op=td.ReduceOp.SUM)
+    if _host_staged(bucket):
+        hb = bucket.cpu()
+        td.all_reduce(hb, op=td.ReduceOp.SUM)
+        bucket.copy_(hb)
+    else:
+        td.all_reduce(bucket, op=td.ReduceOp.SUM)
     o = 0
     for p in ps:
         k = p.numel()
@@ -128,5 +168,10 @@ def allreduce_flat(flat):
     there is no pack / unpack)."""
     td = _dist()
     if td is not None:
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        if _host_staged(flat):
+            h = flat.cpu()
+            td.all_reduce(h, op=td.ReduceOp.SUM)
+            flat.copy_(h)
+        else:
+            td.all_reduce(flat, op=td.ReduceOp.SUM)
     return flat

@@ -2,7 +2,8 @@
 reference: zero_grad -> elbo_bpd -> backward -> clip -> optimizer.step), with the data-parallel
 exchange of SURVEY.md 8e when a process group is up: the loss is normalised by the GLOBAL number of
 pairs, gradients are summed in one flat bucket, and `log_prob` applies every rank's (t, kl) to the
-importance-sampling history so replicas stay identical."""
+importance-sampling history so replicas stay identical.  Two collectives per step: one all-gather of
+[pair count, t, kl] between forward and backward, one all-reduce of the gradient arena after it."""
 import math
 
 import torch
@@ -47,7 +48,10 @@ def train_step(model, batch, optimizer, clip_value=None, clip_norm=None, state=N
         optimizer.zero_grad(set_to_none=True)
     with train.use_arena(arena):
         neg_vb = model.log_prob(batch, **log_prob_kwargs)                   # [B], differentiable
-        P = shard.sum_over_ranks_device(batch.num_entries, batch.device)   # global pair count, no host sync
+        # global pair count: gathered together with (t, kl) inside log_prob (one collective), no host sync
+        P = batch.__dict__.pop('_global_entries', None)
+        if P is None:
+            P = shard.sum_over_ranks_device(batch.num_entries, batch.device)
         loss = -neg_vb.sum() / (math.log(2) * P)                            # diffusion/loss.py:10-12
         loss.backward()
     if arena is not None:

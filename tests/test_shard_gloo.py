@@ -88,6 +88,11 @@ def _train_worker(rank, world, port, q):
     Pd = shard.sum_over_ranks_device(10 + rank, 'cpu')
     assert torch.is_tensor(Pd) and Pd.dtype == torch.float32 and float(Pd) == P
     t_all = shard.all_gather_cat(torch.tensor([rank * 2, rank * 2 + 1]))
+    # the single per-step all-gather of the training step: [pair count, t, kl] of every rank
+    Pg, tg, klg = shard.gather_step_scalars(746031 + rank, torch.tensor([5 + rank, 500 - rank]),
+                                            torch.tensor([0.25 + rank, 1e-20 * (rank + 1)]))
+    assert float(Pg) == 746031 * 2 + 1 and tg.dtype == torch.int64 and tg.tolist() == [5, 500, 6, 499]
+    assert klg.dtype == torch.float32 and torch.equal(klg, torch.tensor([0.25, 1e-20, 1.25, 2e-20]))
     td.barrier()
     td.destroy_process_group()
     q.put((rank, params[0].grad.tolist(), params[1].grad.tolist(), params[2].grad, P, t_all.tolist(), bucket.numel()))
