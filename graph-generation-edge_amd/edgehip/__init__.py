@@ -8,4 +8,5 @@ from .model import (BinomialDiffusionActive, TGNN_degree_guided, add_model_args,
 from .sampler import EmpiricalEmptyGraphGenerator  # noqa: F401
 from . import shard  # noqa: F401
 from .trainer import make_optimizer, train_step  # noqa: F401
-from .stats import edge_overlap, graph_statistics  # noqa: F401
+from . import stats  # noqa: F401
+from .stats import NetworkEvaluator, edge_overlap, graph_statistics  # noqa: F401

@@ -84,6 +84,7 @@ EXPORTS = {
                             C.POINTER(Rng), vp, vp, vp, C.c_size_t, vp],
     'edgehip_linear_fwd': [vp, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp],
     'edgehip_graph_stats': [C.POINTER(Layout), vp, vp, vp, vp],
+    'edgehip_graph_stats_ext': [C.POINTER(Layout), vp, vp, vp, vp, vp],
     'edgehip_edge_overlap': [C.POINTER(Layout), vp, vp, vp, vp],
     # training ops (csrc/train.hip)
     'edgehip_train_embed_fwd': [C.POINTER(Layout), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp],

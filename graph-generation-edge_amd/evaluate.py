@@ -88,7 +88,7 @@ def main(argv=None):
             G.add_nodes_from(range(d.num_nodes))
             G.add_edges_from(d.edge_index.t().tolist())
             lcc.append(len(max(nx.connected_components(G), key=len)))
-        res['LCC'] = lcc
+        res['LCC_networkx'] = lcc
     print(json.dumps(res))
     if a.out:
         with open(a.out, 'w') as fh:

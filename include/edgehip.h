@@ -421,6 +421,16 @@ int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P,
 #define EDGEHIP_NSTAT 10
 int edgehip_graph_stats(const edgehip_layout* L, const uint32_t* adj, const int32_t* deg, int64_t* out, void* stream);
 
+/* replaces: LCC (eval_utils/graph_statistics.py:60-73), square_count (:126-143) and cpl (:233-246) of
+ *           compute_graph_statistics (:249-285), again as exact integer sums from the bit matrix.
+ * ext [B][4] int64: 0 sum over node pairs i<j of c(c-1), c = common neighbours (square_count = that / 4);
+ *   1 sum of shortest-path lengths over ordered pairs (i,j), j != i reachable from i; 2 the number of such pairs
+ *   (cpl = 1 / 2); 3 size of the largest connected component.
+ * labels [Nn] int32 out: component label of every node = LOCAL id of the smallest node of its component
+ * (min-label propagation with pointer jumping, one block per graph); work [Nn] int32 scratch. */
+int edgehip_graph_stats_ext(const edgehip_layout* L, const uint32_t* adj, int32_t* labels, int32_t* work, int64_t* ext,
+                            void* stream);
+
 /* replaces: edge_overlap, eval_utils/graph_statistics.py:287-299.  out[B] = popcount(A & B) per graph
  * (= 2 x shared edges) for two states of the same layout. */
 int edgehip_edge_overlap(const edgehip_layout* L, const uint32_t* adj_a, const uint32_t* adj_b, int64_t* out,

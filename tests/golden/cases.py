@@ -71,3 +71,16 @@ def dropout_masks(useed, num_nodes, p, layers=len(HEADS), dim=DIM):
     TGNN_degree_guided.forward (layers.py:357,361): slot 2i = conv output of layer i, slot 2i+1 = its GRU hidden."""
     rng = np.random.default_rng(useed + 7)
     return [torch.from_numpy((rng.random((num_nodes, dim)) >= p).astype(np.uint8)) for _ in range(2 * layers)]
+
+
+def stats_graphs():
+    """Graphs of the statistics fixture (stats.npz): ragged incl. degenerate ones, a sparse random graph with several
+    components, a path (long diameter), two disjoint cliques, and the polblogs shape."""
+    rng = np.random.default_rng(41)
+    gs = [g for g in ragged_graphs(6)]
+    gs.append(dict(n=150, edges=random_graph(rng, 150, 0.012)))
+    gs.append(dict(n=40, edges=np.stack([np.arange(39), np.arange(1, 40)], 1).astype(np.int64)))
+    a = np.stack(np.triu_indices(9, 1), 1)
+    gs.append(dict(n=21, edges=np.concatenate([a, a + 9]).astype(np.int64)))          # 2 cliques + 3 isolated nodes
+    gs.append(polblogs_graph(0)[0])
+    return gs

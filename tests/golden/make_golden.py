@@ -469,6 +469,50 @@ def gen_traj_big(case='polblogs1'):
           f'smallest |margin| {float(np.min(np.abs(rec["min_margin"]))):.3e}')
 
 
+def gen_stats():
+    """compute_graph_statistics of the reference (eval_utils/graph_statistics.py:249-285) on the fixture graphs, and
+    NetworkEvaluator.evaluate's NMAE dict (datasets/evaluator.py:32-37; that module needs dgl to import, so its two
+    lines are applied here to the reference statistics).  Stand-ins: `powerlaw` is absent - its Fit for this call is
+    restated (PARITY UNPINNED for power_law_exp); `nx.from_scipy_sparse_matrix` (removed in networkx 3) is aliased to
+    its successor so that LCC / triangles / assortativity take their intended path instead of the bare `except`."""
+    print('graph statistics')
+    import networkx as nx
+    pl = types.ModuleType('powerlaw')
+
+    class Fit:
+        def __init__(self, data, xmin=None, verbose=False):
+            d = np.asarray(data, dtype=np.float64)
+            d = d[d > 0]
+            d = d[d >= xmin]
+            self.power_law = types.SimpleNamespace(alpha=1.0 + len(d) / np.sum(np.log(d / xmin)))
+    pl.Fit = Fit
+    sys.modules['powerlaw'] = pl
+    if not hasattr(nx, 'from_scipy_sparse_matrix'):
+        nx.from_scipy_sparse_matrix = nx.from_scipy_sparse_array
+    import warnings
+    from eval_utils.graph_statistics import compute_graph_statistics
+    keys = None
+    rows = []
+    for g in cases.stats_graphs():
+        G = nx.Graph()
+        G.add_nodes_from(range(g['n']))
+        G.add_edges_from(np.asarray(g['edges']).reshape(-1, 2).tolist())
+        A = nx.to_scipy_sparse_array(G).astype(np.float64) if g['n'] > 0 else None
+        with warnings.catch_warnings(), np.errstate(all='ignore'):
+            warnings.simplefilter('ignore')
+            st = compute_graph_statistics(A)
+        keys = keys or list(st.keys())
+        rows.append([float(np.asarray(st[k]).reshape(-1)[0]) if np.size(st[k]) else np.nan for k in keys])
+        print('   ', g['n'], {k: round(v, 4) for k, v in zip(keys, rows[-1])})
+    rows = np.array(rows, dtype=np.float64)
+    # NetworkEvaluator: reference = the polblogs-shaped graph (last), targets = the three graphs before it
+    ref, tg = rows[-1], rows[-4:-1]
+    with np.errstate(all='ignore'):
+        mean = tg.mean(0)
+        nmae = np.abs((mean - ref) / ref)
+    save('stats.npz', keys=np.array(keys), values=rows, nmae=nmae, nmae_mean=mean)
+
+
 def synth_deg(g):
     from edgehip import synth
     return synth.degrees(g['n'], g['edges']).astype(np.float32)
@@ -483,6 +527,9 @@ if __name__ == '__main__':
             gen_loss('polblogs1', [100], tag='_dp', dp=0.1)
         finally:
             torch.rand_like = real_rand_like
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'stats':
+        gen_stats()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'trajbig':
         try:
@@ -504,6 +551,8 @@ if __name__ == '__main__':
         gen_loss('polblogs1', [100], tag='_dp', dp=0.1)
         gen_traj('toy')
         gen_traj('ragged')
+        gen_traj_big('polblogs1')
+        gen_stats()
     finally:
         torch.rand_like = real_rand_like
     print('golden vectors written; oracle == reference on every case')

@@ -42,7 +42,7 @@ def test_evaluate_script_loads_checkpoint_and_samples(tmp_path):
     assert out.num_graphs == 5 and len(res['triangle_count']) == 5
     assert json.load(open(tmp_path / 'stats.json'))['num_edges'] == res['num_edges']
     assert sum(res['num_edges']) == out.edge_index.shape[1]
-    assert all(1 <= l <= n for l, n in zip(res['LCC'], res['nodes']))
+    assert all(1 <= l <= n for l, n in zip(res['LCC'], res['nodes'])) and res['LCC'] == res['LCC_networkx']
     # same weights, same seeds -> the same graphs as sampling from the in-memory model
     res2, out2 = ev.main(argv)
     assert torch.equal(out.edge_index, out2.edge_index)

@@ -143,3 +143,25 @@ def test_synthetic_polblogs_shape():
     assert (e[:, 0] < e[:, 1]).all()
     n2, e2 = synth.polblogs_like(0)
     assert np.array_equal(e, e2)
+
+
+def test_degree_only_statistics_against_the_reference_fixture():
+    """power law / gini / edge-distribution entropy are host formulas over the device's degree vector
+    (eval_utils/graph_statistics.py:146-199); here on degrees computed with numpy from the same graphs."""
+    import cases
+    from edgehip import stats, synth
+    g = np.load(os.path.join(cases.GOLDEN_DIR, 'stats.npz'), allow_pickle=False)
+    keys = [str(k) for k in g['keys']]
+    fns = {'power_law_exp': stats.power_law_alpha, 'gini': stats.gini, 'rel_edge_distr_entropy': stats.edge_distribution_entropy}
+    n = 0
+    for gi, x in enumerate(cases.stats_graphs()):
+        d = synth.degrees(x['n'], x['edges']) if len(x['edges']) else np.zeros(x['n'])
+        for k, f in fns.items():
+            ref = g['values'][gi, keys.index(k)]
+            got = f(d)
+            if np.isfinite(ref):
+                assert abs(got - ref) <= 1e-12 * max(1.0, abs(ref)), (gi, k, got, ref)
+                n += 1
+            else:
+                assert not np.isfinite(got) or (k == 'gini' and x['n'] == 1), (gi, k, got, ref)
+    assert n >= 18
