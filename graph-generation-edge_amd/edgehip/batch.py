@@ -96,7 +96,9 @@ class GraphBatch:
                                                                 capi.stream_ptr()), 'degree_from_adj')
                 self.degree_i32 = deg
                 self.degree = deg.long()
-        self._slice_dict, self._inc_dict = {}, {}
+        # PyG bookkeeping the reference's epilogue fixes up (diffusion_base.py:227-228): per-graph offsets that
+        # `separate` subtracts from an index attribute = the first node of each graph
+        self._slice_dict, self._inc_dict = {}, {'full_edge_index': self._t['node_ptr'][:-1].long()}
 
     # ---- helpers -------------------------------------------------------------------------
     def _dev(self):
@@ -199,16 +201,45 @@ class GraphBatch:
     def full_edge_attr(self):
         return self.pair_bits()
 
-    def to_data_list(self):
-        """Per-graph results with local node ids, like PyG's Batch.to_data_list()."""
-        ei = self.edge_index.cpu()
+    def local_edge_index(self):
+        """edge_index with LOCAL node ids ([2,E] int64 on the device, one pass): what PyG's `separate` produces per
+        graph by subtracting `_inc_dict['edge_index']` (diffusion_base.py:221-228)."""
+        sl = self._slice_dict['edge_index']
+        inc = self._inc_dict['edge_index']
+        per_edge = torch.repeat_interleave(inc, sl[1:] - sl[:-1], output_size=int(self.edge_index.shape[1]))
+        return self.edge_index - per_edge[None, :]
+
+    def to_data_list(self, device=None):
+        """Per-graph results with local node ids, like PyG's `Batch.to_data_list()` (consumer: experiment.py:70,
+        evaluate.py:51).  The per-graph `edge_index` / `edge_attr` / `node_attr` are VIEWS of three tensors
+        (no per-graph copies): on the batch's device with device='cuda' / self.device, else (default) of ONE pinned
+        host copy of the whole edge list - a single D2H transfer however many graphs there are."""
         sl = self._slice_dict['edge_index'].cpu().tolist()
+        ei = self.local_edge_index()
+        ea, na = self.edge_attr, self.node_attr
+        if device is None or torch.device(device).type == 'cpu':
+            if ei.is_cuda:
+                host = torch.empty(ei.shape, dtype=ei.dtype, pin_memory=True)
+                host.copy_(ei)
+                ei = host
+            ea, na = ea.cpu(), na.cpu()
         out = []
         for b in range(self.num_graphs):
-            e = ei[:, sl[b]:sl[b + 1]] - int(self.host.node_ptr[b])
-            out.append(SimpleNamespace(edge_index=e, num_nodes=int(self.host.nodes_per_graph[b]),
-                                       edge_attr=torch.ones(e.shape[1], dtype=torch.long),
-                                       node_attr=torch.zeros(int(self.host.nodes_per_graph[b]), dtype=torch.long)))
+            n0, n1 = int(self.host.node_ptr[b]), int(self.host.node_ptr[b + 1])
+            out.append(SimpleNamespace(edge_index=ei[:, sl[b]:sl[b + 1]], num_nodes=n1 - n0,
+                                       edge_attr=ea[sl[b]:sl[b + 1]], node_attr=na[n0:n1]))
+        return out
+
+    def to_networkx(self):
+        """list of undirected networkx graphs (`pyg.utils.to_networkx(d, to_undirected=True)` per graph,
+        experiment.py:70-75): one host copy of the edge list, numpy views per graph."""
+        import networkx as nx
+        out = []
+        for d in self.to_data_list():
+            G = nx.Graph()
+            G.add_nodes_from(range(d.num_nodes))
+            G.add_edges_from(d.edge_index.numpy().T.tolist())
+            out.append(G)
         return out
 
 

@@ -734,7 +734,7 @@ class BinomialDiffusionActive(nn.Module):
         if training:     # active.py:250-254; under data parallelism every replica applies every rank's pairs
             from . import shard
             # one all-gather carries the local pair count and every rank's (t, kl)
-            batch._global_entries, t_all, kl_all = shard.gather_step_scalars(batch.num_pairs, t, kl)
+            batch._global_entries, t_all, kl_all = shard.gather_step_scalars(batch.num_pairs, t, kl.detach())
             Lt2 = kl_all.pow(2)
             prev = self.Lt_history.gather(dim=0, index=t_all)
             self.Lt_history.scatter_(dim=0, index=t_all, src=(0.1 * Lt2 + 0.9 * prev))

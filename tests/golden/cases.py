@@ -84,3 +84,15 @@ def stats_graphs():
     gs.append(dict(n=21, edges=np.concatenate([a, a + 9]).astype(np.int64)))          # 2 cliques + 3 isolated nodes
     gs.append(polblogs_graph(0)[0])
     return gs
+
+
+def sampler_train_graphs():
+    """Training set of the empty-graph sampler fixture: repeated sizes (so `random.choice` matters), a gap in the
+    size histogram, one graph without edges."""
+    rng = np.random.default_rng(51)
+    sizes = [12, 33, 12, 70, 33, 12, 5, 33, 40]
+    ps = [0.4, 0.2, 0.3, 0.15, 0.25, 0.5, 0.0, 0.1, 0.2]
+    return [dict(n=n, edges=random_graph(rng, n, p) if p > 0 else np.zeros((0, 2), np.int64)) for n, p in zip(sizes, ps)]
+
+
+SAMPLER_SEED, SAMPLER_DRAWS = 123, 25

@@ -513,6 +513,57 @@ def gen_stats():
     save('stats.npz', keys=np.array(keys), values=rows, nmae=nmae, nmae_mean=mean)
 
 
+def gen_sampler():
+    """EmpiricalEmptyGraphGenerator of the reference (datasets/data_utils.py:78-147) under a seed: the ORDER and
+    COUNT of its RNG draws is the contract (one torch multinomial for all sizes, then one `random.choice` per graph).
+    The module needs torch_geometric: Data / Batch are attribute bags here (clone, from_data_list = concatenation of
+    the per-graph tensors), which is all `sample()` asks of them."""
+    print('empty-graph sampler')
+    import copy
+    import random
+    pyg = sys.modules['torch_geometric']
+    pyg.data = types.ModuleType('torch_geometric.data')
+    pyg.transforms = types.ModuleType('torch_geometric.transforms')
+    pyg.utils.to_dense_adj = None
+    pyg.utils.from_networkx = None
+
+    class Data:
+        def clone(self):
+            return copy.deepcopy(self)
+
+    class Batch(Data):
+        @staticmethod
+        def from_data_list(ds):
+            b = Batch()
+            b.num_graphs = len(ds)
+            b.degree = torch.cat([d.degree for d in ds])
+            b.node_attr = torch.cat([d.node_attr for d in ds])
+            b.full_edge_attr = torch.cat([d.full_edge_attr for d in ds])
+            b.batch = torch.cat([torch.full((d.num_nodes,), i, dtype=torch.long) for i, d in enumerate(ds)])
+            return b
+    pyg.data.Data, pyg.data.Batch = Data, Batch
+    for mod in (pyg.data, pyg.transforms):
+        sys.modules[mod.__name__] = mod
+    from datasets.data_utils import EmpiricalEmptyGraphGenerator
+    train = []
+    for g in cases.sampler_train_graphs():
+        d = Data()
+        d.num_nodes = g['n']
+        e = torch.as_tensor(np.asarray(g['edges']).reshape(-1, 2), dtype=torch.long).t()
+        d.edge_index = torch.cat([e, e.flip(0)], dim=1)          # bi-directional, as pyg.utils.from_networkx gives it
+        train.append(d)
+    gen = EmpiricalEmptyGraphGenerator(train, degree=True)
+    torch.manual_seed(cases.SAMPLER_SEED)
+    random.seed(cases.SAMPLER_SEED)
+    b1 = gen.sample(cases.SAMPLER_DRAWS)
+    b2 = gen.sample(7)                                            # a second call continues both RNG streams
+    save('sampler.npz', size_dist=gen.empirical_graph_size_dist, min_node=gen.min_node, max_node=gen.max_node,
+         nodes_per_graph_1=b1.nodes_per_graph, edges_per_graph_1=b1.edges_per_graph, degree_1=b1.degree,
+         nodes_per_graph_2=b2.nodes_per_graph, edges_per_graph_2=b2.edges_per_graph, degree_2=b2.degree,
+         degree_dtype=str(b1.degree.dtype))
+    print('    sizes', b1.nodes_per_graph.tolist())
+
+
 def synth_deg(g):
     from edgehip import synth
     return synth.degrees(g['n'], g['edges']).astype(np.float32)
@@ -527,6 +578,9 @@ if __name__ == '__main__':
             gen_loss('polblogs1', [100], tag='_dp', dp=0.1)
         finally:
             torch.rand_like = real_rand_like
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'sampler':
+        gen_sampler()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'stats':
         gen_stats()
@@ -553,6 +607,7 @@ if __name__ == '__main__':
         gen_traj('ragged')
         gen_traj_big('polblogs1')
         gen_stats()
+        gen_sampler()
     finally:
         torch.rand_like = real_rand_like
     print('golden vectors written; oracle == reference on every case')

@@ -172,6 +172,39 @@ def test_sample_trajectory_vs_reference_golden(case):
     assert np.array_equal(b._slice_dict['edge_index'].cpu().numpy(), g['edge_slice'])
     dl = b.to_data_list()
     assert [d.edge_index.shape[1] for d in dl] == np.diff(g['edge_slice']).tolist()
+    _check_consumer_format(b, g['edge_index'], g['edge_slice'])
+
+
+def _check_consumer_format(b, edge_index, edge_slice):
+    """What the reference's callers do with the result (experiment.py:70-75, evaluate.py:51-58): to_data_list(),
+    per-graph local ids, networkx hand-off; here as views of one tensor, on the host (one pinned D2H copy) or on the
+    device, never one copy per graph."""
+    import networkx as nx
+    node_ptr = b.host.node_ptr
+    assert np.array_equal(b._inc_dict['edge_index'].cpu().numpy(), node_ptr[:-1])         # diffusion_base.py:228
+    for dev in (None, 'cuda'):
+        dl = b.to_data_list(device=dev)
+        assert len(dl) == b.num_graphs
+        base = None
+        for k, d in enumerate(dl):
+            want = edge_index[:, edge_slice[k]:edge_slice[k + 1]] - node_ptr[k]
+            assert d.edge_index.is_cuda == (dev == 'cuda')
+            assert np.array_equal(d.edge_index.cpu().numpy(), want)
+            assert d.num_nodes == node_ptr[k + 1] - node_ptr[k] and d.node_attr.shape[0] == d.num_nodes
+            assert d.edge_attr.shape[0] == want.shape[1] and bool((d.edge_attr == 1).all())
+            if want.shape[1]:
+                st = d.edge_index.untyped_storage().data_ptr()
+                base = st if base is None else base
+                assert st == base                                                           # views of ONE tensor
+        if dev is None and base is not None:
+            assert next(d for d in dl if d.edge_index.shape[1]).edge_index.is_pinned()
+    gs = b.to_networkx()
+    for k, G in enumerate(gs):
+        want = edge_index[:, edge_slice[k]:edge_slice[k + 1]] - node_ptr[k]
+        H2 = nx.Graph()
+        H2.add_nodes_from(range(int(node_ptr[k + 1] - node_ptr[k])))
+        H2.add_edges_from(want.T.tolist())
+        assert G.number_of_nodes() == H2.number_of_nodes() and set(map(frozenset, G.edges)) == set(map(frozenset, H2.edges))
 
 
 def test_fused_sampler_matches_stepwise_and_is_shard_invariant():

@@ -165,3 +165,25 @@ def test_degree_only_statistics_against_the_reference_fixture():
             else:
                 assert not np.isfinite(got) or (k == 'gini' and x['n'] == 1), (gi, k, got, ref)
     assert n >= 18
+
+
+def test_empty_graph_sampler_draws_like_the_reference_under_a_seed():
+    """tests/golden/sampler.npz: the reference's EmpiricalEmptyGraphGenerator (datasets/data_utils.py:78-147) seeded
+    with torch.manual_seed + random.seed.  Same sizes, same chosen degree sequences, same batch fields - over two
+    consecutive sample() calls, so the number of RNG draws per call matches too."""
+    import random
+    import cases
+    import edgehip
+    g = np.load(os.path.join(cases.GOLDEN_DIR, 'sampler.npz'), allow_pickle=False)
+    train = [(x['n'], x['edges']) for x in cases.sampler_train_graphs()]
+    gen = edgehip.EmpiricalEmptyGraphGenerator(train, degree=True, device='cpu')
+    assert gen.min_node == int(g['min_node']) and gen.max_node == int(g['max_node'])
+    assert np.array_equal(gen.empirical_graph_size_dist.numpy(), g['size_dist'])
+    torch.manual_seed(cases.SAMPLER_SEED)
+    random.seed(cases.SAMPLER_SEED)
+    for tag, k in (('1', cases.SAMPLER_DRAWS), ('2', 7)):
+        b = gen.sample(k)
+        assert np.array_equal(b.nodes_per_graph.numpy(), g['nodes_per_graph_' + tag])
+        assert np.array_equal(b.edges_per_graph.numpy(), g['edges_per_graph_' + tag])
+        assert str(b.degree.dtype) == str(g['degree_dtype']) and np.array_equal(b.degree.numpy(), g['degree_' + tag])
+        assert b.num_graphs == k and int(b.adj.abs().sum()) == 0                   # x_T input: empty graphs
