@@ -57,7 +57,7 @@ def test_reverse_step_vs_oracle_other_shapes(shape, t_step):
     assert np.array_equal(b._state['deg_t'][:Nn].cpu().numpy().astype(np.int64), rec['degree_t'].numpy())
     assert np.array_equal(ani.cpu().numpy(), rec['active_node_indices'].numpy())
     assert np.array_equal(aei.cpu().numpy(), rec['active_edge_indices'].numpy())
-    assert H.rel_err(want['logits'], rec['logits']) < TOL
+    H.check_logits(want['logits'], rec['logits'], TOL)
     # a flip needs |margin| below the fp32 noise of the logits; count instead of assuming none
     bits = want['bits'].cpu().numpy().astype(np.int64)
     flips = int((bits != rec['sampled_bits'].numpy()).sum())
@@ -188,7 +188,12 @@ def test_config2_ego_T128_batch8_loss_and_gradient_vs_oracle():
     # (rounding drift ~1e-4, see test_train_loss_vs_reference_golden) and count x value in fp64 here
     np.testing.assert_allclose(want['kl'].cpu().numpy(), rec['kl'].detach().numpy(), rtol=TOL, atol=1e-12)
     np.testing.assert_allclose(want['kl_prior'].cpu().numpy(), rec['kl_prior'].numpy(), rtol=5e-4)
-    np.testing.assert_allclose(nv.detach().cpu().numpy(), nv_ref.detach().numpy(), rtol=5e-4)
+    # against the reference formula with that one fp32 accumulation done in fp64 the 1e-4 bound holds everywhere:
+    prior64 = H.kl_prior_fp64(o, ob)
+    np.testing.assert_allclose(want['kl_prior'].cpu().numpy().astype(np.float64), prior64.numpy(), rtol=1e-6)
+    nv64 = -(rec['kl'].detach().double() / pt.double() + prior64)
+    np.testing.assert_allclose(nv.detach().cpu().numpy().astype(np.float64), nv64.numpy(), rtol=TOL)
+    np.testing.assert_allclose(nv.detach().cpu().numpy(), nv_ref.detach().numpy(), rtol=5e-4)   # raw fp32-summed reference
     (-nv.sum() / (np.log(2) * b.num_entries)).backward()
     gmax = max(float(r.grad.abs().max()) for r in po.values() if r.grad is not None)
     for k, v in model._denoise_fn.named_parameters():

@@ -241,7 +241,7 @@ def test_loss_gradient_vs_oracle_autograd(name, case, form):
     assert nv.requires_grad
     np.testing.assert_allclose(nv.detach().cpu().numpy(), g['neg_vb'], rtol=1e-4, atol=1e-12)
     if len(g['logits']):
-        assert H.rel_err(want['logits'], g['logits']) < 1e-4
+        H.check_logits(want['logits'], g['logits'], 1e-4)
     bpd = -nv.sum() / (np.log(2) * b.num_entries)
     bpd.backward()
     named = dict(model._denoise_fn.named_parameters())
@@ -686,7 +686,7 @@ def test_dropout_loss_and_gradients_vs_reference_golden(name, case, form):
     dm = torch.stack(masks).cuda().contiguous()
     nv = model.log_prob(b, t, pt, us[1].cuda(), us[3].cuda(), want, dropout_masks=dm)
     np.testing.assert_allclose(nv.detach().cpu().numpy(), g['neg_vb'], rtol=1e-4, atol=1e-12)
-    assert H.rel_err(want['logits'], g['logits']) < 1e-4
+    H.check_logits(want['logits'], g['logits'], 1e-4)
     # the dropout really acts: the dp 0 golden of the same case differs
     g0 = H.golden(name[:-3] + '.npz')
     assert H.rel_err(want['logits'], g0['logits']) > 1e-3
