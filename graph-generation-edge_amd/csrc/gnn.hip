@@ -919,6 +919,19 @@ extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) 
     return EDGEHIP_OK;
 }
 
+// Block barrier of the fused layer kernel.  Its waves only exchange data through LDS, so a barrier has to wait for the
+// LDS queue alone (s_waitcnt lgkmcnt(0)).  __syncthreads() is a workgroup fence + s_barrier, and for the fence hipcc
+// drains the VECTOR-memory queue too (s_waitcnt vmcnt(0)): every barrier then waits for the global stores of h' and
+// for every weight fragment or gather requested ahead, which is exactly the latency the prefetches are meant to hide.
+#ifndef EH_LDS_BARRIER
+#define EH_LDS_BARRIER 1
+#endif
+#if EH_LDS_BARRIER
+#define EH_BLOCK_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define EH_BLOCK_SYNC() __syncthreads()
+#endif
+
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
 #define EH_TSZ (32 * EH_TP)
 
@@ -1010,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         const int i = tid + it * 256;
         *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
     }
-    __syncthreads();
+    EH_BLOCK_SYNC();
     EH_STAMP_AT(0);
 
     // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it
@@ -1040,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             for (int i = 0; i < 16; ++i) qz[eh_crow(i, lane) * QP + col] = acc[i] + qb;
         }
     }
-    __syncthreads();
+    EH_BLOCK_SYNC();
     EH_STAMP_AT(1);
 
     // ---- phase B: attention of the light rows, z overwrites qt.
@@ -1221,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
         EH_SUB_AT(11);
     }
-    __syncthreads();
+    EH_BLOCK_SYNC();
     EH_STAMP_AT(2);
 
     // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1).  wave = (column tile ct, K half kh):
@@ -1255,12 +1268,12 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_to_pfrag(af, af0);
             eh_mma64(acc, af, bf);
         }
-        __syncthreads();                      // every wave is done reading qz
+        EH_BLOCK_SYNC();                      // every wave is done reading qz
         EH_STAMP_AT(3);
         float* mine = pt + wave * EH_TSZ;
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_TP + r] = acc[i];
-        __syncthreads();
+        EH_BLOCK_SYNC();
         const float* p0 = pt + (c0 >> 5) * EH_TSZ + row * EH_TP + (c0 & 31);      // K half 0 of this column tile
         const bool hasnbr = dl[row] > 0;
 #pragma unroll
@@ -1277,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0 + 4 * q4) = v;
         }
     }
-    __syncthreads();
+    EH_BLOCK_SYNC();
     EH_STAMP_AT(4);
 
     // ---- phase D: GRU.  wave = (column tile ct, gate part): part 0 -> r and i_n, part 1 -> z and h_n
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_load_frag_packed(bf, a.w_hh, 1, ct, 0, lane);     eh_mma64(g0, ah, bf);
             eh_load_frag_packed(bf, a.w_ih, 1, 4 + ct, 0, lane); eh_mma64(g1, am, bf);
         }
-        __syncthreads();
+        EH_BLOCK_SYNC();
         if (part == 0) {
             const float bir = bA, bin = bB;
 #pragma unroll
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             }
         }
     }
-    __syncthreads();
+    EH_BLOCK_SYNC();
     EH_STAMP_AT(5);
 
     // ---- phase E: context pre-activation column sums
