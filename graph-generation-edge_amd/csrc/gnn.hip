@@ -220,11 +220,23 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
 // --------------------------------------------------------------------------------------------
 // workspace carving
 // --------------------------------------------------------------------------------------------
+// Heavy-row counters of a step, one zero-filled int32 block: [0] heavy rows, [1] long rows (one 64-bit atomic for both),
+// [2..9] long rows per XCD, [16 + g] heavy rows of graph g.
+#define EH_HC_LONG 2
+#define EH_HC_GRAPH 16
+#define EH_HC_INTS(B) (EH_HC_GRAPH + (size_t)(B) + 16)
+// Heavy rows are walked on the XCD that owns their graph: graphs are dealt to the 8 XCDs in contiguous ranges, the
+// same ranges the fused layer kernel's tile order gives them, so a graph's h rows (313 KB for polblogs) are gathered
+// through ONE L2 instead of all eight.
+__host__ __device__ static inline int eh_xcd_of_graph(int g, int B) { return (int)((long long)g * 8 / B); }
+__host__ __device__ static inline int eh_xcd_first_graph(int x, int B) { return (int)(((long long)x * B + 7) / 8); }
+
 struct eh_ws {
     float *hA, *hB, *Qt, *Z, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
     // step-level scratch
     int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_nodes, *heavy_slot, *heavy_count;
-    int32_t* long_slots;   // slots of the longest heavy rows (k_attn_heavy starts them first)
+    int32_t* long_slots;   // slots of the longest heavy rows, one list per XCD (k_attn_heavy starts them first)
+    int32_t *heavy_pg, *heavy_out;   // per-graph heavy lists (slot = node_ptr[g] + k): node, compact index
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
     float* cwgt;
     int64_t* aptr;
@@ -252,8 +264,10 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.cbias = (float*)take((B + 1) * 256 * 4);
     w.deg = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
-    w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4); w.heavy_count = (int32_t*)take(256);
-    w.long_slots = (int32_t*)take(NnP * 4);
+    w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4);
+    w.heavy_count = (int32_t*)take(EH_HC_INTS(B) * 4);
+    w.long_slots = (int32_t*)take(8 * NnP * 4);
+    w.heavy_pg = (int32_t*)take(NnP * 4); w.heavy_out = (int32_t*)take(NnP * 4);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
     w.ccount = (int32_t*)take((B + 1) * 4);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
@@ -424,7 +438,8 @@ struct eh_prep_args {
     int max_degree; const float *at, *a0, *as;
     const int32_t *deg, *d0; const uint8_t* flags; const int32_t* idle;
     float *h0, *part;
-    int32_t *heavy_count, *heavy_nodes, *heavy_slot, *long_slots;
+    int32_t *heavy_count, *heavy_nodes, *heavy_slot, *long_slots, *heavy_pg, *heavy_out;
+    int long_stride;           // entries per XCD in long_slots
     int dedupe; int32_t* crow; float* cwgt; int32_t *rep_of, *ccount;
     int tile_blocks;
 };
@@ -449,17 +464,28 @@ __global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_
         const bool hv = d > EH_HEAVY_DEG, lg = d > EH_LONG_DEG;
         const unsigned long long mh = __ballot(hv), ml = __ballot(lg);
         const unsigned long long below = (1ull << lane) - 1ull;
-        int baseh = 0, basel = 0;
-        if (lane == 0 && mh) {       // both counters in one 64-bit atomic (low word: heavy rows, high word: long rows)
-            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(p.heavy_count),
-                                                     (unsigned long long)__popcll(mh) | ((unsigned long long)__popcll(ml) << 32));
-            baseh = (int)(old & 0xffffffffull); basel = (int)(old >> 32);
+        const int g = L.tile_graph[tile];
+        const int xcd = eh_xcd_of_graph(g, L.num_graphs);
+        // the four counters of this tile in ONE atomic instruction (lanes 0-3, one address each): total heavy rows,
+        // total long rows, heavy rows of the graph, long rows of the XCD - one memory round trip, not four
+        int mine = 0;
+        if (lane < 4 && mh) {
+            const int off = lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? EH_HC_GRAPH + g : EH_HC_LONG + xcd));
+            const int add = (lane & 1) ? __popcll(ml) : __popcll(mh);
+            if (add) mine = atomicAdd(p.heavy_count + off, add);
         }
-        baseh = __shfl(baseh, 0); basel = __shfl(basel, 0);
-        int slot = -1;
-        if (hv) { slot = baseh + __popcll(mh & below); p.heavy_nodes[slot] = i; }
-        if (lg) p.long_slots[basel + __popcll(ml & below)] = slot;
-        if (lane < rows) p.heavy_slot[i] = slot;
+        const int baseh = __shfl(mine, 0), baseg = __shfl(mine, 2), basel = __shfl(mine, 3);
+        // two lists: the compact one (any order; q~ / z of the row live at Qt[cidx], Z[cidx], and the gathered-row q~
+        // GEMM runs over it) and the graph's own (slot = node_ptr[g] + k), through which k_attn_heavy finds the rows
+        // of the graphs of its XCD
+        int slot = -1, cidx = -1;
+        if (hv) {
+            const int rk = __popcll(mh & below);
+            slot = L.node_ptr[g] + baseg + rk; cidx = baseh + rk;
+            p.heavy_nodes[cidx] = i; p.heavy_pg[slot] = i; p.heavy_out[slot] = cidx;
+        }
+        if (lg) p.long_slots[(size_t)xcd * p.long_stride + basel + __popcll(ml & below)] = slot;
+        if (lane < rows) p.heavy_slot[i] = cidx;
     }
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
@@ -796,9 +822,10 @@ template <int HEADS>
 __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
                                                     const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
                                                     const float* __restrict__ qbias, int ldq,
-                                                    const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_nodes,
+                                                    const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_pg,
+                                                    const int32_t* __restrict__ heavy_cidx,
                                                     const int32_t* __restrict__ deg, const int32_t* __restrict__ long_slots,
-                                                    float* __restrict__ zheavy) {
+                                                    int long_stride, float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
 #ifndef EH_HCHUNK
@@ -806,29 +833,32 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
 #endif
     __shared__ uint32_t list[32 * EH_HCHUNK + 16];  // a chunk holds at most 32 * EH_HCHUNK neighbours (+ step padding)
     const int lane = threadIdx.x;
-    const int nheavy = *counter;
     const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS, head = grp % HEADS;
-    // XCD affinity: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the contiguous slice
-    // [x*nheavy/8, (x+1)*nheavy/8) of the list, which is roughly in node order, so an XCD touches the h rows
-    // of ~B/8 graphs (a few MB: L2-resident) instead of all of them.  Affinity only; any placement is correct.
-    const int xcd = blockIdx.x & 7, nloc = (gridDim.x + 7 - xcd) >> 3;      // blocks of this XCD
-    const int s0 = (int)((int64_t)nheavy * xcd / 8), s1 = (int)((int64_t)nheavy * (xcd + 1) / 8);
-    // work of this block: first the long rows (blocks are dispatched in index order, so the rows that take
-    // longest start first), then its share of the XCD slice without them
-    const int nlong = counter[1];
-    for (int it = blockIdx.x;; it += gridDim.x) {
+    // XCD ownership: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the heavy rows of ITS graphs
+    // (eh_xcd_of_graph: contiguous ranges of B/8 graphs, the ranges k_layer's tile order gives the XCDs), so a
+    // graph's h rows are gathered through one L2 only.  Affinity only; any placement is correct.
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nloc = (gridDim.x + 7 - xcd) >> 3;   // this XCD's blocks: jb of nloc
+    const int g0 = eh_xcd_first_graph(xcd, L.num_graphs), g1 = eh_xcd_first_graph(xcd + 1, L.num_graphs);
+    int total = 0;                                                    // heavy rows of this XCD's graphs
+    for (int gg = g0; gg < g1; ++gg) total += counter[EH_HC_GRAPH + gg];
+    // work of this block: first the XCD's long rows (blocks are dispatched in index order, so the rows that take
+    // longest start first), then its share of the XCD's per-graph lists without them
+    const int nlong = counter[EH_HC_LONG + xcd];
+    const int first = nlong > jb ? (nlong - jb + nloc - 1) / nloc : 0;   // long rows this block takes
+    int gcur = g0, gbase = 0;                                         // cursor into the per-graph lists (indices only grow)
+    for (int round = 0;; ++round) {
         int idx;
-        if (it < nlong) {
-            idx = long_slots[it];
+        if (round < first) {
+            idx = long_slots[(size_t)xcd * long_stride + jb + round * nloc];
         } else {
-            // after its long rows (block-uniform count) the block walks the slice
-            const int first = nlong > (int)blockIdx.x ? (nlong - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-            idx = s0 + (blockIdx.x >> 3) + ((it - (int)blockIdx.x) / (int)gridDim.x - first) * nloc;
-            if (idx >= s1) break;
-            if (deg[heavy_nodes[idx]] > EH_LONG_DEG) continue;
+            const int li = jb + (round - first) * nloc;               // index into the concatenation of the XCD's lists
+            if (li >= total) break;
+            while (gcur < g1 && li >= gbase + counter[EH_HC_GRAPH + gcur]) { gbase += counter[EH_HC_GRAPH + gcur]; ++gcur; }
+            idx = L.node_ptr[gcur] + (li - gbase);
+            if (deg[heavy_pg[idx]] > EH_LONG_DEG) continue;
         }
-        const int node = heavy_nodes[idx];
+        const int node = heavy_pg[idx], cidx = heavy_cidx[idx];
         const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
@@ -838,7 +868,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
         {
             // qt row of the gathered GEMM + the per-graph bias (time embedding / context terms)
             f32x2 qb[EH_CPL / 2];
-            eh_load_cpl(q, qheavy + (size_t)idx * H + head * 64 + c * EH_CPL);
+            eh_load_cpl(q, qheavy + (size_t)cidx * H + head * 64 + c * EH_CPL);
             eh_load_cpl(qb, qbias + (size_t)g * ldq + head * 64 + c * EH_CPL);
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] += qb[d]; acc[d] = f32x2{0.f, 0.f}; }
@@ -864,7 +894,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
         }
         eh_merge_slots<HEADS>(acc, m, lsum);
-        if (slot == 0) eh_store_cpl_scaled(zheavy + (size_t)idx * H + head * 64 + c * EH_CPL, acc, 1.0f / (lsum + 1e-16f));
+        if (slot == 0) eh_store_cpl_scaled(zheavy + (size_t)cidx * H + head * 64 + c * EH_CPL, acc, 1.0f / (lsum + 1e-16f));
     }
 }
 
@@ -1518,13 +1548,13 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    (void)hipMemsetAsync(w.heavy_count, 0, 8, s);       // [0] heavy rows, [1] long rows among them
+    (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);       // totals, long rows per XCD, heavy rows per graph
     {
         eh_prep_args pa = {};
         pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
         pa.deg = deg; pa.d0 = d0; pa.flags = flags; pa.idle = idle; pa.h0 = w.hA; pa.part = w.part;
         pa.heavy_count = w.heavy_count; pa.heavy_nodes = w.heavy_nodes; pa.heavy_slot = w.heavy_slot;
-        pa.long_slots = w.long_slots;
+        pa.long_slots = w.long_slots; pa.heavy_pg = w.heavy_pg; pa.heavy_out = w.heavy_out; pa.long_stride = Nn + 32;
         pa.dedupe = h_out ? 0 : 1; pa.crow = w.crow; pa.cwgt = w.cwgt; pa.rep_of = w.rep_of; pa.ccount = w.ccount;
         pa.tile_blocks = tile_blocks;
         EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_step_prepare, dim3(tile_blocks + B), dim3(256), 0, s, *L, pa));
@@ -1573,10 +1603,10 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         }
         const int hb = Nn < 16384 ? Nn : 16384;          // single-wave blocks
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_nodes, deg, w.long_slots, w.Z)); break;
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
         }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
