@@ -116,6 +116,31 @@ __device__ static inline void eh_mma64(f32x16& acc, const eh_frag3& a, const eh_
         acc = EH_MFMA_BF16(a.h[i], b.h[i], acc);
     }
 }
+// ---- fp32 weight tiles split while they are staged (training GEMMs: the weights change every step) -----
+// LDS image of a [32 x 64] weight tile as three bf16 planes in FRAGMENT order: dword offset of (row r, k) =
+// hh*528 + i*132 + r*4 + (k&7)/2 with hh = k>>5, i = (k&31)>>3.  A lane's operand group i is one 16-byte read
+// (conflict-free: the 16 lanes of a b128 group differ in r); the staging thread's four consecutive k are one
+// 8-byte write per plane (132 = 4 mod 32 and 528 = 16 mod 32: the 16 (hh, i, half) writers of a row hit all 32 banks).
+#define EH_W3_PLANE 1056
+typedef unsigned int eh_u32x2 __attribute__((ext_vector_type(2)));
+__device__ static inline void eh_stage3_quad(unsigned* __restrict__ tile, int row, int k0, const f32x4& v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    eh_split_pair(v[0], v[1], h0, m0, l0);
+    eh_split_pair(v[2], v[3], h1, m1, l1);
+    unsigned* p = tile + (row >> 5) * 3 * EH_W3_PLANE + (k0 >> 5) * 528 + ((k0 & 31) >> 3) * 132 + (row & 31) * 4 + ((k0 & 7) >> 1);
+    *reinterpret_cast<eh_u32x2*>(p) = eh_u32x2{h0, h1};
+    *reinterpret_cast<eh_u32x2*>(p + EH_W3_PLANE) = eh_u32x2{m0, m1};
+    *reinterpret_cast<eh_u32x2*>(p + 2 * EH_W3_PLANE) = eh_u32x2{l0, l1};
+}
+__device__ static inline void eh_load_frag3_lds(eh_frag3& f, const unsigned* tile, int j, int r, int hh) {
+    const unsigned* p = tile + j * 3 * EH_W3_PLANE + hh * 528 + r * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f.h[i] = *reinterpret_cast<const eh_u32x4*>(p + i * 132);
+        f.m[i] = *reinterpret_cast<const eh_u32x4*>(p + EH_W3_PLANE + i * 132);
+        f.l[i] = *reinterpret_cast<const eh_u32x4*>(p + 2 * EH_W3_PLANE + i * 132);
+    }
+}
 // split weights in fragment order (k_pack_w): tile (nt, kc) = 3 planes (h, m, l) x [i = 0..3][lane][8 bf16];
 // 3072 float-sized words per tile, every load a coalesced 1-KiB row
 #define EH_PK_TILE 3072

@@ -8,7 +8,7 @@
 // at ~130 VGPRs), which wins once a launch has several blocks per CU; the pipelined form below (236 VGPRs, one
 // block per CU) wins on the small, latency-bound launches.  eh_launch_gemm picks by block count.
 template <int NACC>
-__device__ static inline void eh_gemm_lds_body_simple(const eh_gemm_desc& d, int ng_per_block, int bx, int by, float* wt) {
+__device__ static inline void eh_gemm_lds_body_simple(const eh_gemm_desc& d, int ng_per_block, int bx, int by, unsigned* wt) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int nw = 4;
     int tile = bx * nw + wave;
@@ -38,21 +38,26 @@ __device__ static inline void eh_gemm_lds_body_simple(const eh_gemm_desc& d, int
     const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
     const bool single = d.K == 64;
     eh_frag a;
-    if (single) eh_load_frag(a, ap);
+    eh_frag3 a3;
+    if (single) { eh_load_frag(a, ap); eh_split3(a3, a); }
     for (int ng = ng0; ng < ng1; ++ng) {
         f32x16 acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
         for (int kc = 0; kc < d.K; kc += 64) {
             __syncthreads();
-            eh_stage_w<NACC * 32>(wt, d.W, d.K, ng * NACC * 32, kc);
             if (!single) eh_load_frag(a, (kc < d.K1) ? ap + kc : ap2 + (kc - d.K1));
+            for (int i = threadIdx.x; i < NACC * 32 * 16; i += 256) {
+                const int row = i >> 4, c4 = (i & 15) * 4;
+                eh_stage3_quad(wt, row, c4, *reinterpret_cast<const f32x4*>(d.W + (size_t)(ng * NACC * 32 + row) * d.K + kc + c4));
+            }
+            if (!single) eh_split3(a3, a);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
-                eh_frag b;
-                eh_load_frag_lds(b, wt, j * 32 + r, hh);
-                eh_mma64(acc[j], a, b);
+                eh_frag3 b;
+                eh_load_frag3_lds(b, wt, j, r, hh);
+                eh_mma64(acc[j], a3, b);
             }
         }
         if (!live) continue;
@@ -91,8 +96,8 @@ __device__ static inline void eh_gemm_lds_body_simple(const eh_gemm_desc& d, int
 // trip.  The earlier form (barrier, stage, barrier, MFMA per trip) left the matrix pipe idle during every
 // staging round trip: measured on the training step in DESIGN.md 5b.
 template <int NACC>
-__device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by, float* wt) {
-    constexpr int TSZ = NACC * 32 * EH_WPITCH;     // floats per weight tile; wt holds two
+__device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by, unsigned* wt) {
+    constexpr int TSZ = NACC * 3 * EH_W3_PLANE;    // dwords per split weight tile; wt holds two
     constexpr int NLD = NACC * 32 * 16 / 256;      // float4 per thread and tile (256 threads)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     int tile = bx * 4 + wave;
@@ -130,15 +135,17 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
 #pragma unroll
         for (int i = 0; i < NLD; ++i) wr[i] = *reinterpret_cast<const f32x4*>(src + (size_t)i * 16 * d.K);
     };
-    auto wstore = [&](float* buf) {
+    auto wstore = [&](unsigned* buf) {          // split into the three bf16 planes on the way into LDS
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(buf + (srow + 16 * i) * EH_WPITCH + sc4) = wr[i];
+        for (int i = 0; i < NLD; ++i) eh_stage3_quad(buf, srow + 16 * i, sc4, wr[i]);
     };
     auto aload = [&](eh_frag& f, int kci) { eh_load_frag(f, (kci * 64 < d.K1) ? ap + kci * 64 : ap2 + (kci * 64 - d.K1)); };
-    eh_frag a, an;
+    eh_frag an;
+    eh_frag3 a;
     wload(ng0, 0);
-    aload(a, 0);
+    aload(an, 0);
     wstore(wt);
+    eh_split3(a, an);
     __syncthreads();
     f32x16 acc[NACC];
 #pragma unroll
@@ -152,11 +159,11 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
             wload(ngn, kcn);
             if (KC > 1) aload(an, kcn);
         }
-        const float* cur = wt + (it & 1) * TSZ;
+        const unsigned* cur = wt + (it & 1) * TSZ;
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
-            eh_frag b;
-            eh_load_frag_lds(b, cur, j * 32 + r, hh);
+            eh_frag3 b;
+            eh_load_frag3_lds(b, cur, j, r, hh);
             eh_mma64(acc[j], a, b);
         }
         if (kci == KC - 1) {
@@ -193,7 +200,7 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
         }
         if (more) {
             wstore(wt + ((it + 1) & 1) * TSZ);
-            if (KC > 1) a = an;
+            if (KC > 1) eh_split3(a, an);
         }
         ng = ngn; kci = kcn;
         __syncthreads();
@@ -202,7 +209,7 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
 
 template <int NACC, bool PIPE>
 __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) {
-    __shared__ __attribute__((aligned(16))) float wt[(PIPE ? 2 : 1) * NACC * 32 * EH_WPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned wt[(PIPE ? 2 : 1) * NACC * 3 * EH_W3_PLANE];
     if (PIPE) eh_gemm_lds_body<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
     else eh_gemm_lds_body_simple<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
 }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) 
 // cost about as much together as the largest of them alone.
 template <int NACC, bool PIPE>
 __global__ __launch_bounds__(256) void k_gemm_group(eh_gemm_group g) {
-    __shared__ __attribute__((aligned(16))) float wt[(PIPE ? 2 : 1) * NACC * 32 * EH_WPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned wt[(PIPE ? 2 : 1) * NACC * 3 * EH_W3_PLANE];
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= g.gx[z] || (int)blockIdx.y >= g.split[z]) return;
     if (PIPE) eh_gemm_lds_body<NACC>(g.d[z], g.per[z], blockIdx.x, blockIdx.y, wt);
