@@ -359,7 +359,7 @@ def main():
                         'value': a.train_steps / tel, 'unit': 'steps/s', 'ms_per_step': 1e3 * tel / a.train_steps,
                         'graphs_per_step': TB * world, 'last_bpd': float(bpd)}
         # roofline of the step: algorithmic flops of fwd + bwd at the mean (E_t, A) of 16 more (untimed) steps with
-        # the same t distribution, against the fp32 matrix peak (the products are fp32 MFMA here)
+        # the same t distribution, against the fp32 matrix peak (the products run as exact-split bf16 MFMAs, priced as fp32 work)
         As, Es = [], []
         for _ in range(16):
             edgehip.train_step(tmodel, tb, opt, clip_value=1.0, state=tstate)

@@ -268,3 +268,87 @@ def test_polblogs_scale_training_steps_agree_with_the_inference_kernels():
         assert np.isfinite(float(bpd))
         assert bool(torch.isfinite(state['arena'].flat).all()) if 'arena' in state else True
     assert float((model._denoise_fn.node_in[0].weight.detach() - w0).abs().max()) > 0
+
+
+def _degenerate_graphs():
+    """n = 1 (no pair at all), n = 2 with and without its edge, a path, a star across the 32-row tile boundary, a clique
+    next to isolated nodes, a graph with no edge, a hub of degree 96 (heavy row, more than one step of 64 words)."""
+    def star(n):
+        return np.array([(0, j) for j in range(1, n)], dtype=np.int64).reshape(-1, 2)
+    clique = np.array([(i, j) for i in range(10) for j in range(i + 1, 10)], dtype=np.int64)
+    return [dict(n=1, edges=np.zeros((0, 2), np.int64)),
+            dict(n=2, edges=np.array([[0, 1]], np.int64)),
+            dict(n=2, edges=np.zeros((0, 2), np.int64)),
+            dict(n=3, edges=np.array([[0, 1], [1, 2]], np.int64)),
+            dict(n=33, edges=star(33)),
+            dict(n=64, edges=clique),
+            dict(n=65, edges=np.zeros((0, 2), np.int64)),
+            dict(n=97, edges=star(97))]
+
+
+def test_degenerate_graphs_trajectory_and_loss_vs_oracle():
+    """Edge cases of the batch layout in ONE ragged batch (see _degenerate_graphs): whole reverse trajectories against
+    the oracle run live on the same uniforms (final edge lists identical), then the training loss of the same batch."""
+    from edgehip import synth
+    gs = _degenerate_graphs()
+    T = 24
+    dmax = cases.max_degree_of(gs)
+    params = orc.random_tgnn_params(21)
+    Nn = sum(x['n'] for x in gs)
+    P = sum(x['n'] * (x['n'] - 1) // 2 for x in gs)
+    rng = np.random.default_rng(77)
+    o = orc.EdgeOracle(params, T, dmax)
+    ob = orc.make_batch([dict(n=x['n'], edges=None, degree=synth.degrees(x['n'], x['edges'])) for x in gs])
+    with torch.no_grad():
+        o.sample(ob, orc.CallbackTape(lambda tag, shape: cases.uniforms(rng, *shape)))
+    model = H.build_model(params, T, dmax)
+    b = H.graph_batch(gs, with_edges=False)
+    rng = np.random.default_rng(77)
+    cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)          # prior draws (always the empty graph)
+    for t in reversed(range(T)):
+        u_act = cases.uniforms(rng, Nn, 2).cuda()
+
+        def pair_u(A):
+            cases.uniforms(rng, Nn, 2)
+            return cases.uniforms(rng, A, 2).cuda()
+        model.p_sample(b, t, u_act, pair_u)
+    model._finish_sample(b)
+    assert np.array_equal(b.edge_index.cpu().numpy(), ob.edge_index.numpy())
+    assert np.array_equal(b._slice_dict['edge_index'].cpu().numpy(), ob.edge_slice.numpy())
+    # the fused sampler on the same batch layout runs and keeps every graph within its own nodes
+    fb = model.sample_batch(H.graph_batch(gs, with_edges=False), seed=5)
+    ptr = np.concatenate([[0], np.cumsum([x['n'] for x in gs])])
+    sl = fb._slice_dict['edge_index'].cpu().numpy()
+    ei = fb.edge_index.cpu().numpy()
+    for g in range(len(gs)):
+        e = ei[:, sl[g]:sl[g + 1]]
+        assert e.size == 0 or (e.min() >= ptr[g] and e.max() < ptr[g + 1] and (e[0] < e[1]).all())
+    assert sl[1] - sl[0] == 0 and sl[3] - sl[2] == 0 and sl[7] - sl[6] == 0     # n = 1 and the d0 = 0 graphs stay empty
+
+    # training loss of the true graphs at mixed t (incl. 0 and T-1), with gradients
+    t = torch.tensor([0, 1, 5, 23, 7, 12, 3, 9], dtype=torch.int64)
+    pt = torch.full((len(gs),), 1.0 / T)
+    rng = np.random.default_rng(78)
+    us = [cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2), cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)]
+    po = {k: v.clone().requires_grad_() for k, v in params.items()}
+    o = orc.EdgeOracle(po, T, dmax)
+    otb = orc.make_batch(gs, degree_dtype=torch.int64)
+    otb.log_node_attr = orc.index_to_log_onehot(otb.node_attr)
+    otb.log_full_edge_attr = orc.index_to_log_onehot(otb.full_edge_attr)
+    rec = {}
+    nv_ref = o.loss(otb, t, pt, orc.UniformTape(us), training=True, record=rec)
+    orc.elbo_bpd(nv_ref, otb.num_entries).backward()
+    model.train()
+    tb = H.graph_batch(gs, degree_dtype=np.int64)
+    want = {}
+    nv = model.log_prob(tb, t, pt, us[1].cuda(), us[3].cuda(), want)
+    np.testing.assert_allclose(want['kl'].cpu().numpy(), rec['kl'].detach().numpy(), rtol=TOL, atol=1e-12)
+    np.testing.assert_allclose(nv.detach().cpu().numpy(), nv_ref.detach().numpy(), rtol=TOL, atol=1e-5)   # tiny graphs: -vb is rounding noise of the prior KL
+    (-nv.sum() / (np.log(2) * tb.num_entries)).backward()
+    gmax = max(float(r.grad.abs().max()) for r in po.values() if r.grad is not None)
+    for k, v in model._denoise_fn.named_parameters():
+        ref = po[k].grad
+        if ref is None:
+            continue
+        scale = max(float(ref.abs().max()), 1e-6 * gmax)
+        assert float((v.grad.cpu().double() - ref.double()).abs().max()) / scale < 2e-4, k
