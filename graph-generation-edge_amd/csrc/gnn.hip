@@ -220,11 +220,11 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
 // --------------------------------------------------------------------------------------------
 // workspace carving
 // --------------------------------------------------------------------------------------------
-// Heavy-row counters of a step, one zero-filled int32 block: [0] heavy rows, [1] long rows (one 64-bit atomic for both),
-// [2..9] long rows per XCD, [16 + g] heavy rows of graph g.
-#define EH_HC_LONG 2
-#define EH_HC_GRAPH 16
-#define EH_HC_INTS(B) (EH_HC_GRAPH + (size_t)(B) + 16)
+// Heavy-row counters of a step, one zero-filled int32 block: [g] heavy rows of graph g that are not long,
+// [EH_HC_LONG(B) + g] its long rows.  Per graph, not per launch: a counter that every tile of the launch adds to is
+// one address at the memory side, ~15 ns per add (2 496 tiles: 37 us of k_step_prepare's 41).
+#define EH_HC_LONG(B) ((B) + 16)
+#define EH_HC_INTS(B) (2 * ((size_t)(B) + 16))
 // Heavy rows are walked on the XCD that owns their graph: graphs are dealt to the 8 XCDs in contiguous ranges, the
 // same ranges the fused layer kernel's tile order gives them, so a graph's h rows (313 KB for polblogs) are gathered
 // through ONE L2 instead of all eight.
@@ -234,9 +234,10 @@ __host__ __device__ static inline int eh_xcd_first_graph(int x, int B) { return 
 struct eh_ws {
     float *hA, *hB, *Qt, *Z, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
     // step-level scratch
-    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_nodes, *heavy_slot, *heavy_count;
-    int32_t* long_slots;   // slots of the longest heavy rows, one list per XCD (k_attn_heavy starts them first)
-    int32_t *heavy_pg, *heavy_out;   // per-graph heavy lists (slot = node_ptr[g] + k): node, compact index
+    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_slot, *heavy_count;
+    // per-graph heavy lists inside the graph's own node range: slot -> node.  Heavy rows fill [node_ptr[g], ..) upwards,
+    // the long ones among them (node_ptr[g+1], ..] downwards; q~ and z of a heavy row live at row `slot` of Qt / Z
+    int32_t* heavy_pg;
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
     float* cwgt;
     int64_t* aptr;
@@ -264,10 +265,9 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.cbias = (float*)take((B + 1) * 256 * 4);
     w.deg = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
-    w.heavy_nodes = (int32_t*)take(NnP * 4); w.heavy_slot = (int32_t*)take(NnP * 4);
+    w.heavy_slot = (int32_t*)take(NnP * 4);
     w.heavy_count = (int32_t*)take(EH_HC_INTS(B) * 4);
-    w.long_slots = (int32_t*)take(8 * NnP * 4);
-    w.heavy_pg = (int32_t*)take(NnP * 4); w.heavy_out = (int32_t*)take(NnP * 4);
+    w.heavy_pg = (int32_t*)take(NnP * 4);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
     w.ccount = (int32_t*)take((B + 1) * 4);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
@@ -438,8 +438,7 @@ struct eh_prep_args {
     int max_degree; const float *at, *a0, *as;
     const int32_t *deg, *d0; const uint8_t* flags; const int32_t* idle;
     float *h0, *part;
-    int32_t *heavy_count, *heavy_nodes, *heavy_slot, *long_slots, *heavy_pg, *heavy_out;
-    int long_stride;           // entries per XCD in long_slots
+    int32_t *heavy_count, *heavy_slot, *heavy_pg;
     int dedupe; int32_t* crow; float* cwgt; int32_t *rep_of, *ccount;
     int tile_blocks;
 };
@@ -457,47 +456,46 @@ __global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_
     if (tile >= L.num_tiles) return;
     if (eh_graph_idle(p.idle, L.tile_graph[tile])) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
-    {   // heavy rows get a slot in the compact list (any order: slots are independent); one atomic per wave.
-        // The longest rows are listed a second time: k_attn_heavy starts them first (they set its tail).
-        const int i = row0 + lane;
-        const int d = lane < rows ? deg[i] : 0;
-        const bool hv = d > EH_HEAVY_DEG, lg = d > EH_LONG_DEG;
-        const unsigned long long mh = __ballot(hv), ml = __ballot(lg);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int g = L.tile_graph[tile];
-        const int xcd = eh_xcd_of_graph(g, L.num_graphs);
-        // the four counters of this tile in ONE atomic instruction (lanes 0-3, one address each): total heavy rows,
-        // total long rows, heavy rows of the graph, long rows of the XCD - one memory round trip, not four
-        int mine = 0;
-        if (lane < 4 && mh) {
-            const int off = lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? EH_HC_GRAPH + g : EH_HC_LONG + xcd));
-            const int add = (lane & 1) ? __popcll(ml) : __popcll(mh);
-            if (add) mine = atomicAdd(p.heavy_count + off, add);
-        }
-        const int baseh = __shfl(mine, 0), baseg = __shfl(mine, 2), basel = __shfl(mine, 3);
-        // two lists: the compact one (any order; q~ / z of the row live at Qt[cidx], Z[cidx], and the gathered-row q~
-        // GEMM runs over it) and the graph's own (slot = node_ptr[g] + k), through which k_attn_heavy finds the rows
-        // of the graphs of its XCD
-        int slot = -1, cidx = -1;
-        if (hv) {
-            const int rk = __popcll(mh & below);
-            slot = L.node_ptr[g] + baseg + rk; cidx = baseh + rk;
-            p.heavy_nodes[cidx] = i; p.heavy_pg[slot] = i; p.heavy_out[slot] = cidx;
-        }
-        if (lg) p.long_slots[(size_t)xcd * p.long_stride + basel + __popcll(ml & below)] = slot;
-        if (lane < rows) p.heavy_slot[i] = cidx;
+    // heavy rows get a slot in their graph's list (any order: slots are independent): one atomic instruction per
+    // wave (lane 0: the graph's heavy rows that are not long, lane 1: its long rows).  The long rows are listed apart
+    // because k_attn_heavy starts them first (they set its tail).  The result is first used after the h0 rows below.
+    const int hi = row0 + lane;
+    const int hd = lane < rows ? deg[hi] : 0;
+    const bool lg = hd > EH_LONG_DEG, hv = hd > EH_HEAVY_DEG && !lg;
+    const unsigned long long mh = __ballot(hv), ml = __ballot(lg);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int hg = L.tile_graph[tile];
+    int mine = 0;
+    if (lane < 2) {
+        const int add = lane ? __popcll(ml) : __popcll(mh);
+        if (add) mine = atomicAdd(p.heavy_count + (lane ? EH_HC_LONG(L.num_graphs) : 0) + hg, add);
     }
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
     float sum = 0.f;
+    // the three per-row inputs of the whole tile in one request per array (lane r holds row r); the row loop then
+    // reads them from registers instead of waiting for three dependent loads per row
+    const int li = row0 + (lane < rows ? lane : 0);
+    int dtl = deg[li];
+    dtl = dtl > max_degree + 1 ? max_degree + 1 : dtl;
+    const float xtl = (float)dtl / md, x0l = (float)d0[li] / md;
+    const int fll = flags[li];
     for (int r = 0; r < rows; ++r) {
         int i = row0 + r;
-        int dt = deg[i];
-        dt = dt > max_degree + 1 ? max_degree + 1 : dt;
-        float xt = (float)dt / md, x0 = (float)d0[i] / md;
-        float v = eh_silu(vat * xt + va0 * x0 + (flags[i] ? vs1 : vs0));
+        const float xt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xtl), r));
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0l), r));
+        const int fl = __builtin_amdgcn_readlane(fll, r);
+        float v = eh_silu(vat * xt + va0 * x0 + (fl ? vs1 : vs0));
         h0[(size_t)i * 64 + lane] = v;
         sum += v;
+    }
+    {
+        const int baseh = __shfl(mine, 0), basel = __shfl(mine, 1);
+        int slot = -1;
+        if (hv) slot = L.node_ptr[hg] + baseh + __popcll(mh & below);
+        if (lg) slot = L.node_ptr[hg + 1] - 1 - (basel + __popcll(ml & below));
+        if (slot >= 0) p.heavy_pg[slot] = hi;
+        if (lane < rows) p.heavy_slot[hi] = slot;
     }
     part[(size_t)tile * 256 + lane] = sum;
 }
@@ -609,11 +607,75 @@ __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_
                          u.obias1, u.cbias, u.idle, u.ccount, blockIdx.x / EH_GU_PARTS, blockIdx.x % EH_GU_PARTS);
 }
 
+// q~ of the heavy rows: Y[slot] = Mcat h[heavy_pg[slot]] over the graphs' slot lists.  The rows are enumerated as ONE
+// compact sequence (graph 0's heavy rows, its long rows, graph 1's ..) so that the 32-row tiles are full; a wave finds
+// the (graph, position) of its 32 rows from the per-graph counts with a wave prefix sum (no index array, no counter
+// that every tile of a launch would have to add to).
+struct eh_hq_args {
+    const float* A; const float* W; float* Y; int H;         // h rows [*,64], packed Mcat, q~ [slot][H]
+    const int32_t *seg_ptr, *seg_lo, *seg_hi, *row_of; int nseg;
+};
+__device__ static inline void eh_heavy_qt_body(const eh_hq_args& d, int ng_per_block, int bx, int by) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m0 = (bx * 4 + wave) * 32;
+    int run = 0, myg = 0, myk = 0;
+    for (int base = 0; base < d.nseg; base += 64) {
+        const int gi = base + lane;
+        int incl = gi < d.nseg ? d.seg_lo[gi] + d.seg_hi[gi] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (run + tot > m0 && run < m0 + 32) {
+            for (int rr = 0; rr < 32; ++rr) {
+                const int mr = m0 + rr - run;                           // wave-uniform
+                if (mr < 0 || mr >= tot) continue;
+                const int q = __popcll(__ballot(incl <= mr));          // graphs of this chunk that end at or before mr
+                const int before = q ? __builtin_amdgcn_readlane(incl, q - 1) : 0;
+                if ((lane & 31) == rr) { myg = base + q; myk = mr - before; }
+            }
+        }
+        run += tot;
+    }
+    if (m0 >= run) return;
+    const int rows = run - m0 < 32 ? run - m0 : 32;
+    const int r = lane & 31, hh = lane >> 5;
+    {   // rows past the end repeat the last one (computed, not stored)
+        const int src = (r < rows ? r : rows - 1) + (lane & 32);
+        myg = __shfl(myg, src); myk = __shfl(myk, src);
+    }
+    const int lo = d.seg_lo[myg];
+    const int slot = myk < lo ? d.seg_ptr[myg] + myk : d.seg_ptr[myg + 1] - 1 - (myk - lo);
+    const float* ap = d.A + (size_t)d.row_of[slot] * 64 + hh * 32;
+    eh_frag a;
+    eh_pfrag a3;
+    eh_load_frag(a, ap);
+    eh_to_pfrag(a3, a);
+    int yrow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yrow[i] = __shfl(slot, eh_crow(i, lane));
+    const int ng_total = d.H / 32;
+    const int ng0 = by * ng_per_block;
+    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
+    for (int ng = ng0; ng < ng1; ++ng) {
+        f32x16 acc = eh_zero16();
+        eh_pfrag b;
+        eh_load_frag_packed(b, d.W, 1, ng, 0, lane);
+        eh_mma64(acc, a3, b);
+        const int col = ng * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (eh_crow(i, lane) < rows) d.Y[(size_t)yrow[i] * d.H + col] = acc[i];
+    }
+}
+
 // One launch, two independent jobs side by side (block specialisation): the per-graph update of layer l
 // (blocks [0, nb_update)) and the gathered-row qt GEMM of the heavy rows (the rest).  Neither reads what the
 // other writes; run back to back they were two latency-bound launches on the critical path of every layer.
 __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, edgehip_gnn_params P, eh_update_args u,
-                                                            int nb_update, eh_gemm_desc d, int gx, int per) {
+                                                            int nb_update, eh_hq_args d, int gx, int per) {
     const int b = blockIdx.x;
     if (b < nb_update) {
         eh_graph_update_body(L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
@@ -622,7 +684,7 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
         const int bb = b - nb_update;
         // one accumulator per wave: 151 instead of 204 registers for the whole kernel, 3 waves per SIMD
         // (single stream 122.5 -> 124.4 graphs/s)
-        eh_gemm_packed_body<1>(d, 2 * per, bb % gx, bb / gx);
+        eh_heavy_qt_body(d, per, bb % gx, bb / gx);
     }
 }
 
@@ -820,12 +882,10 @@ __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m,
 // walks them with eh_walk_list.
 template <int HEADS>
 __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
-                                                    const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[nheavy,H]*/,
+                                                    const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[slot,H]*/,
                                                     const float* __restrict__ qbias, int ldq,
                                                     const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_pg,
-                                                    const int32_t* __restrict__ heavy_cidx,
-                                                    const int32_t* __restrict__ deg, const int32_t* __restrict__ long_slots,
-                                                    int long_stride, float* __restrict__ zheavy) {
+                                                    float* __restrict__ zheavy) {
     constexpr int H = HEADS * 64;
     constexpr int UN = eh_walk_cfg<HEADS>::UN;
 #ifndef EH_HCHUNK
@@ -840,25 +900,28 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
     // graph's h rows are gathered through one L2 only.  Affinity only; any placement is correct.
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nloc = (gridDim.x + 7 - xcd) >> 3;   // this XCD's blocks: jb of nloc
     const int g0 = eh_xcd_first_graph(xcd, L.num_graphs), g1 = eh_xcd_first_graph(xcd + 1, L.num_graphs);
-    int total = 0;                                                    // heavy rows of this XCD's graphs
-    for (int gg = g0; gg < g1; ++gg) total += counter[EH_HC_GRAPH + gg];
-    // work of this block: first the XCD's long rows (blocks are dispatched in index order, so the rows that take
-    // longest start first), then its share of the XCD's per-graph lists without them
-    const int nlong = counter[EH_HC_LONG + xcd];
+    const int32_t* clong = counter + EH_HC_LONG(L.num_graphs);
+    int total = 0, nlong = 0;                                         // heavy / long rows of this XCD's graphs
+    for (int gg = g0; gg < g1; ++gg) { total += counter[gg]; nlong += clong[gg]; }
+    // work of this block: first its share of the XCD's long rows (blocks are dispatched in index order, so the rows
+    // that take longest start first), then its share of the other heavy rows.  Both are concatenations of per-graph
+    // lists, walked with a cursor (indices only grow).
     const int first = nlong > jb ? (nlong - jb + nloc - 1) / nloc : 0;   // long rows this block takes
-    int gcur = g0, gbase = 0;                                         // cursor into the per-graph lists (indices only grow)
+    int gcur = g0, gbase = 0;
     for (int round = 0;; ++round) {
         int idx;
         if (round < first) {
-            idx = long_slots[(size_t)xcd * long_stride + jb + round * nloc];
+            const int li = jb + round * nloc;
+            while (li >= gbase + clong[gcur]) { gbase += clong[gcur]; ++gcur; }
+            idx = L.node_ptr[gcur + 1] - 1 - (li - gbase);
+            if (round + 1 == first) { gcur = g0; gbase = 0; }       // the cursor starts over for the second list
         } else {
-            const int li = jb + (round - first) * nloc;               // index into the concatenation of the XCD's lists
+            const int li = jb + (round - first) * nloc;
             if (li >= total) break;
-            while (gcur < g1 && li >= gbase + counter[EH_HC_GRAPH + gcur]) { gbase += counter[EH_HC_GRAPH + gcur]; ++gcur; }
+            while (li >= gbase + counter[gcur]) { gbase += counter[gcur]; ++gcur; }
             idx = L.node_ptr[gcur] + (li - gbase);
-            if (deg[heavy_pg[idx]] > EH_LONG_DEG) continue;
         }
-        const int node = heavy_pg[idx], cidx = heavy_cidx[idx];
+        const int node = heavy_pg[idx], cidx = idx;
         const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
@@ -1548,13 +1611,12 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);       // totals, long rows per XCD, heavy rows per graph
+    (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);       // heavy and long rows per graph
     {
         eh_prep_args pa = {};
         pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
         pa.deg = deg; pa.d0 = d0; pa.flags = flags; pa.idle = idle; pa.h0 = w.hA; pa.part = w.part;
-        pa.heavy_count = w.heavy_count; pa.heavy_nodes = w.heavy_nodes; pa.heavy_slot = w.heavy_slot;
-        pa.long_slots = w.long_slots; pa.heavy_pg = w.heavy_pg; pa.heavy_out = w.heavy_out; pa.long_stride = Nn + 32;
+        pa.heavy_count = w.heavy_count; pa.heavy_slot = w.heavy_slot; pa.heavy_pg = w.heavy_pg;
         pa.dedupe = h_out ? 0 : 1; pa.crow = w.crow; pa.cwgt = w.cwgt; pa.rep_of = w.rep_of; pa.ccount = w.ccount;
         pa.tile_blocks = tile_blocks;
         EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_step_prepare, dim3(tile_blocks + B), dim3(256), 0, s, *L, pa));
@@ -1591,22 +1653,27 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         // per-graph update of this layer and qt of the heavy rows (gathered-row GEMM into the compact buffer
         // w.Qt) in ONE launch: they are independent, and each alone is a latency-bound launch
         {
-            eh_gemm_desc d = {};
-            d.A = hcur; d.lda = 64; d.K1 = 64; d.arow_index = w.heavy_nodes; d.W = folded + fm.layer[l].pMcat; d.w_packed = 1;
-            d.K = 64; d.N = h * 64; d.Y = w.Qt; d.ldy = h * 64; d.act = 0; d.M = Nn; d.m_dev = w.heavy_count;
-            int gx, split, per, nacc;
-            eh_gemm_grid(d, gx, split, per, nacc);
-            if (nacc != 2) return EDGEHIP_ERR_UNSUPPORTED;
+            eh_hq_args d;
+            d.A = hcur; d.W = folded + fm.layer[l].pMcat; d.Y = w.Qt; d.H = h * 64;
+            d.seg_ptr = L->node_ptr; d.seg_lo = w.heavy_count; d.seg_hi = w.heavy_count + EH_HC_LONG(B); d.row_of = w.heavy_pg;
+            d.nseg = B;
+            // grid for the upper bound Nn rows; the waves past the listed rows leave at once
+            const int gx = (int)((((int64_t)Nn + 31) / 32 + 3) / 4);
+            const int ngt = h * 2;                                  // 32-column groups
+            int split = (2048 + gx - 1) / gx;
+            split = split < 1 ? 1 : (split > ngt ? ngt : split);
+            const int per = (ngt + split - 1) / split;
+            split = (ngt + per - 1) / per;
             const int nbu = B * EH_GU_PARTS;
             EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_update_and_heavy_qt, dim3(nbu + gx * split), dim3(256), 0, s, *L, *P, ua,
                                nbu, d, gx, per));
         }
         const int hb = Nn < 16384 ? Nn : 16384;          // single-wave blocks
         switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.heavy_out, deg, w.long_slots, Nn + 32, w.Z)); break;
+            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
+            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
+            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
+            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
         }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
@@ -1878,21 +1945,24 @@ __global__ __launch_bounds__(256) void k_step_stats(edgehip_layout L, const int3
                                                     long long* __restrict__ out) {
     __shared__ long long red[3][256];
     const int tid = threadIdx.x;
-    long long act = 0, live = 0, dsum = 0, nodes = 0;
+    long long act = 0, live = 0, dsum = 0, nodes = 0, nheavy = 0, nlong = 0;
     for (int g = tid; g < L.num_graphs; g += 256)
-        if (kptr[g + 1] - kptr[g] >= 2) { act += 1; live += ccount[g]; nodes += L.node_ptr[g + 1] - L.node_ptr[g]; }
+        if (kptr[g + 1] - kptr[g] >= 2) {
+            act += 1; live += ccount[g]; nodes += L.node_ptr[g + 1] - L.node_ptr[g];
+            nlong += heavy[EH_HC_LONG(L.num_graphs) + g]; nheavy += heavy[g] + heavy[EH_HC_LONG(L.num_graphs) + g];
+        }
     for (int i = tid; i < L.num_nodes; i += 256) dsum += deg[i];
     red[0][tid] = act; red[1][tid] = live; red[2][tid] = dsum;
-    __shared__ long long rn[256];
-    rn[tid] = nodes;
+    __shared__ long long rn[256], rh[256], rl[256];
+    rn[tid] = nodes; rh[tid] = nheavy; rl[tid] = nlong;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
-        if (tid < d) { red[0][tid] += red[0][tid + d]; red[1][tid] += red[1][tid + d]; red[2][tid] += red[2][tid + d]; rn[tid] += rn[tid + d]; }
+        if (tid < d) { red[0][tid] += red[0][tid + d]; red[1][tid] += red[1][tid + d]; red[2][tid] += red[2][tid + d]; rn[tid] += rn[tid + d]; rh[tid] += rh[tid + d]; rl[tid] += rl[tid + d]; }
         __syncthreads();
     }
     if (tid == 0) {
         out[0] = counts->k_total; out[1] = counts->a_total; out[2] = red[0][0]; out[3] = red[1][0];
-        out[4] = red[0][0] ? heavy[0] : 0; out[5] = red[0][0] ? heavy[1] : 0; out[6] = red[2][0]; out[7] = rn[0];
+        out[4] = rh[0]; out[5] = rl[0]; out[6] = red[2][0]; out[7] = rn[0];
     }
 }
 
