@@ -125,6 +125,76 @@ __global__ __launch_bounds__(256) void k_tr_gemm_tn(const float* __restrict__ dY
     }
 }
 
+// The same product for many rows (M >= TR_TN64_MIN_ROWS, N and K multiples of 64).  k_tr_gemm_tn re-reads a 32-column
+// strip of dY for every 32 columns of X and the other way round, 4 bytes per lane: M N K / 4 bytes from L2 per launch
+// (640 MB for the q/k/v weights of 32 polblogs graphs), which is what its time follows there.  Here a block owns a
+// 64 x 64 tile of dW: 32-row chunks of both operands go through LDS once per block (16-byte loads, half the bytes
+// per flop), each wave multiplies one 32 x 32 quarter, the next chunk is requested before the products of the
+// current one (two LDS buffers, one barrier per chunk).
+#ifndef TR_TN64_MIN_ROWS
+#define TR_TN64_MIN_ROWS 8192
+#endif
+#define TR_TNP 68
+__global__ __launch_bounds__(256) void k_tr_gemm_tn64(const float* __restrict__ dY, const float* __restrict__ X, int64_t M,
+                                                      int N, int K, int rows_per_block, float* dW, float* db) {
+    __shared__ __attribute__((aligned(16))) float ys[2][32 * TR_TNP], xs[2][32 * TR_TNP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wk = wave >> 1;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int c = lane & 31, half = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.z * rows_per_block;
+    int64_t m1 = m0 + rows_per_block;
+    if (m1 > M) m1 = M;
+    if (m0 >= m1) return;                                   // block-uniform
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;        // staging: rows srow and srow + 16, 4 columns
+    f32x4 ry[2], rx[2];
+    auto fetch = [&](int64_t m) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t r = m + srow + 16 * i;
+            const bool ok = r < m1;
+            ry[i] = ok ? *reinterpret_cast<const f32x4*>(dY + r * N + n0 + sc4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[i] = ok ? *reinterpret_cast<const f32x4*>(X + r * K + k0 + sc4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&ys[buf][(srow + 16 * i) * TR_TNP + sc4]) = ry[i];
+            *reinterpret_cast<f32x4*>(&xs[buf][(srow + 16 * i) * TR_TNP + sc4]) = rx[i];
+        }
+    };
+    f32x16 acc = eh_zero16();
+    float bsum = 0.f;
+    fetch(m0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m = m0; m < m1; m += 32) {
+        const bool more = m + 32 < m1;
+        if (more) fetch(m + 32);
+        const float* ya = &ys[buf][half * TR_TNP + wn * 32 + c];
+        const float* xb = &xs[buf][half * TR_TNP + wk * 32 + c];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a = ya[2 * s * TR_TNP], b = xb[2 * s * TR_TNP];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            bsum += a;
+        }
+        if (more) stash(buf ^ 1);
+        buf ^= 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        atomicAdd(dW + (int64_t)(n0 + wn * 32 + eh_crow(i, lane)) * K + k0 + wk * 32 + c, acc[i]);
+    if (db && blockIdx.y == 0 && wk == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (half == 0) atomicAdd(db + n0 + wn * 32 + c, bsum);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C. activations (kind 1 SiLU layers.py act, 2 Mish layers.py:40-42)
 // ------------------------------------------------------------------------------------------------
@@ -643,6 +713,18 @@ extern "C" int edgehip_linear_bwd_weight(const float* dY, const float* X, int64_
                                          float* db, void* stream) {
     EH_CHECK_ARG(dY && X && dW && M >= 0 && N > 0 && K > 0);
     if (M == 0) return EDGEHIP_OK;
+    if (M >= TR_TN64_MIN_ROWS && (N & 63) == 0 && (K & 63) == 0) {
+        const int tiles64 = (N / 64) * (K / 64);
+        int64_t want = (1024 + tiles64 - 1) / tiles64;               // ~1024 blocks in all
+        int64_t rpb = (M + want - 1) / want;
+        rpb = ((rpb + 31) / 32) * 32;
+        if (rpb < 256) rpb = 256;
+        const int gz = (int)((M + rpb - 1) / rpb);
+        EH_PROF(EH_K_TRAIN, eh_stream(stream), hipLaunchKernelGGL(k_tr_gemm_tn64, dim3(N / 64, K / 64, gz), dim3(256), 0,
+                           eh_stream(stream), dY, X, M, N, K, (int)rpb, dW, db));
+        EH_LAUNCH_CHECK();
+        return EDGEHIP_OK;
+    }
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
 #ifndef TR_TN_BLOCKS
 #define TR_TN_BLOCKS 512

@@ -42,7 +42,8 @@ def _dense_adj(graphs):
     return A
 
 
-@pytest.mark.parametrize('M,K,N', [(1, 64, 64), (37, 128, 512), (1222, 192, 64), (4888, 64, 192), (300, 256, 128), (5, 512, 64)])
+@pytest.mark.parametrize('M,K,N', [(1, 64, 64), (37, 128, 512), (1222, 192, 64), (4888, 64, 192), (300, 256, 128), (5, 512, 64),
+                                   (8192, 64, 64), (39104, 128, 512), (20011, 256, 192)])      # large M: the 64 x 64 dW kernel
 def test_linear_backward_vs_torch(M, K, N):
     from edgehip import train
     g = torch.Generator().manual_seed(M + K + N)
