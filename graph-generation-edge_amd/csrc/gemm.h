@@ -37,20 +37,10 @@ static inline __device__ f32x16 eh_zero16() {
     return z;
 }
 
-// ---- weight tiles through LDS -----------------------------------------------------------------
-// All 256 threads of a block copy ROWS weight rows x 64 floats (one k-chunk) with full-line
-// coalesced 16-byte loads into an LDS tile with a 68-float row pitch; a lane then reads its
-// 32-float fragment with eight ds_read_b128 (pitch 68 -> the 16 lanes of a b128 group hit 16
-// different 4-bank slots: conflict-free).
+// ---- 64-wide fp32 tiles in LDS -----------------------------------------------------------------
+// Row pitch 68 floats: a lane reads its 32-float fragment with eight ds_read_b128 and the 16 lanes of a
+// b128 group hit 16 different 4-bank slots (conflict-free).
 #define EH_WPITCH 68
-template <int ROWS>
-__device__ static inline void eh_stage_w(float* __restrict__ dst, const float* __restrict__ W, int ldw, int row0, int kc) {
-    for (int i = threadIdx.x; i < ROWS * 16; i += 256) {
-        int row = i >> 4, c4 = i & 15;
-        f32x4 v = *reinterpret_cast<const f32x4*>(W + (size_t)(row0 + row) * ldw + kc + c4 * 4);
-        *reinterpret_cast<f32x4*>(dst + row * EH_WPITCH + c4 * 4) = v;
-    }
-}
 __device__ static inline void eh_load_frag_lds(eh_frag& f, const float* tile, int row, int hh) {
     const float* p = tile + row * EH_WPITCH + hh * 32;
 #pragma unroll

@@ -4,97 +4,13 @@
 #include "gemm.h"
 #include "prof.h"
 
-// The plain form: barrier, stage the weight tile, barrier, MFMAs.  Latency is hidden by OCCUPANCY (3 blocks per CU
-// at ~130 VGPRs), which wins once a launch has several blocks per CU; the pipelined form below (236 VGPRs, one
-// block per CU) wins on the small, latency-bound launches.  eh_launch_gemm picks by block count.
-template <int NACC>
-__device__ static inline void eh_gemm_lds_body_simple(const eh_gemm_desc& d, int ng_per_block, int bx, int by, unsigned* wt) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int nw = 4;
-    int tile = bx * nw + wave;
-    int ntiles;
-    int64_t M = 0;
-    if (d.tile_row0) {
-        ntiles = d.num_tiles;
-    } else {
-        M = d.m_dev ? (int64_t)(*d.m_dev) : d.M;
-        ntiles = (int)((M + 31) / 32);
-    }
-    if (bx * nw >= ntiles) return;         // block-uniform: nothing to do
-    const bool live = tile < ntiles;               // idle waves still stage weights and hit barriers
-    if (!live) tile = ntiles - 1;
-    int row0, rows, g = 0;
-    if (d.tile_row0) {
-        row0 = d.tile_row0[tile]; rows = d.tile_rows[tile]; g = d.tile_graph[tile];
-    } else {
-        row0 = tile * 32; rows = (int)((M - row0) < 32 ? (M - row0) : 32);
-    }
-    const int r = lane & 31, hh = lane >> 5;
-    const int64_t arow = row0 + (r < rows ? r : rows - 1);
-    const float* ap = d.A + arow * d.lda + hh * 32;
-    const float* ap2 = d.A2 ? d.A2 + arow * d.lda2 + hh * 32 : nullptr;
-    const int ng_total = d.N / (32 * NACC);
-    const int ng0 = by * ng_per_block;
-    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
-    const bool single = d.K == 64;
-    eh_frag a;
-    eh_frag3 a3;
-    if (single) { eh_load_frag(a, ap); eh_split3(a3, a); }
-    for (int ng = ng0; ng < ng1; ++ng) {
-        f32x16 acc[NACC];
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] = eh_zero16();
-        for (int kc = 0; kc < d.K; kc += 64) {
-            __syncthreads();
-            if (!single) eh_load_frag(a, (kc < d.K1) ? ap + kc : ap2 + (kc - d.K1));
-            for (int i = threadIdx.x; i < NACC * 32 * 16; i += 256) {
-                const int row = i >> 4, c4 = (i & 15) * 4;
-                eh_stage3_quad(wt, row, c4, *reinterpret_cast<const f32x4*>(d.W + (size_t)(ng * NACC * 32 + row) * d.K + kc + c4));
-            }
-            if (!single) eh_split3(a3, a);
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) {
-                eh_frag3 b;
-                eh_load_frag3_lds(b, wt, j, r, hh);
-                eh_mma64(acc[j], a3, b);
-            }
-        }
-        if (!live) continue;
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-            const int col = (ng * NACC + j) * 32 + r;
-            float add0 = d.bias ? d.bias[col] : 0.0f;
-            if (d.gbias0) add0 += d.gbias0[(int64_t)g * d.ldg + col];
-            const float add1 = d.gbias1 ? d.gbias1[(int64_t)g * d.ldg + col] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int rr = eh_crow(i, lane);
-                if (rr < rows) {
-                    int64_t grow = row0 + rr;
-                    float v = acc[j][i] + add0;
-                    if (d.gbias1 && d.rowflag[grow] > 0) v += add1;
-                    if (d.act == 1) v = eh_silu(v);
-                    if (d.dact) {
-                        const float x = d.dact[grow * d.ldy + col];
-                        const float sg = 1.0f / (1.0f + expf(-x));
-                        v *= sg * (1.0f + x * (1.0f - sg));
-                    }
-                    if (d.accum == 2) { atomicAdd(d.Y + grow * d.ldy + col, v); continue; }
-                    if (d.accum) v += d.Y[grow * d.ldy + col];
-                    d.Y[grow * d.ldy + col] = v;
-                    if (d.Y2) d.Y2[grow * d.ldy + col] = eh_silu(v);
-                }
-            }
-        }
-    }
-}
-
 // One block = 4 waves = 4 row tiles sharing the weight tiles; the (column group, k chunk) trips of a block run
 // as ONE software-pipelined sequence: the next weight tile (global -> registers) and the next A fragment are
 // requested before the MFMAs of the current trip and land in the other LDS buffer after them, one barrier per
 // trip.  The earlier form (barrier, stage, barrier, MFMA per trip) left the matrix pipe idle during every
-// staging round trip: measured on the training step in DESIGN.md 5b.
+// staging round trip: measured on the training step in DESIGN.md 5b.  With the split-bf16 products it is also
+// the faster form for launches of many blocks per CU (32 polblogs graphs 11.2 -> 10.6 ms per step, 96: 30.4 -> 28.4),
+// so it is the only one.
 template <int NACC>
 __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per_block, int bx, int by, unsigned* wt) {
     constexpr int TSZ = NACC * 3 * EH_W3_PLANE;    // dwords per split weight tile; wt holds two
@@ -207,23 +123,21 @@ __device__ static inline void eh_gemm_lds_body(const eh_gemm_desc& d, int ng_per
     }
 }
 
-template <int NACC, bool PIPE>
-__global__ __launch_bounds__(256) void k_gemm(eh_gemm_desc d, int ng_per_block) {
-    __shared__ __attribute__((aligned(16))) unsigned wt[(PIPE ? 2 : 1) * NACC * 3 * EH_W3_PLANE];
-    if (PIPE) eh_gemm_lds_body<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
-    else eh_gemm_lds_body_simple<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
+template <int NACC>
+__global__ __launch_bounds__(256, 2) void k_gemm(eh_gemm_desc d, int ng_per_block) {
+    __shared__ __attribute__((aligned(16))) unsigned wt[2 * NACC * 3 * EH_W3_PLANE];
+    eh_gemm_lds_body<NACC>(d, ng_per_block, blockIdx.x, blockIdx.y, wt);
 }
 
 // Several independent linear layers in ONE launch: blockIdx.z selects the descriptor.  At the training shapes
 // (a few thousand rows, K <= 512) a launch is latency-bound, so the q/k/v/skip/gru products of one layer
 // cost about as much together as the largest of them alone.
-template <int NACC, bool PIPE>
-__global__ __launch_bounds__(256) void k_gemm_group(eh_gemm_group g) {
-    __shared__ __attribute__((aligned(16))) unsigned wt[(PIPE ? 2 : 1) * NACC * 3 * EH_W3_PLANE];
+template <int NACC>
+__global__ __launch_bounds__(256, 2) void k_gemm_group(eh_gemm_group g) {
+    __shared__ __attribute__((aligned(16))) unsigned wt[2 * NACC * 3 * EH_W3_PLANE];
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= g.gx[z] || (int)blockIdx.y >= g.split[z]) return;
-    if (PIPE) eh_gemm_lds_body<NACC>(g.d[z], g.per[z], blockIdx.x, blockIdx.y, wt);
-    else eh_gemm_lds_body_simple<NACC>(g.d[z], g.per[z], blockIdx.x, blockIdx.y, wt);
+    eh_gemm_lds_body<NACC>(g.d[z], g.per[z], blockIdx.x, blockIdx.y, wt);
 }
 
 template <int NACC>
@@ -246,9 +160,6 @@ void eh_gemm_grid(const eh_gemm_desc& d, int& gx, int& split, int& per, int& nac
 // N is not a multiple of 64).  Cutting small problems finer (one wave per block, 32 columns per wave: 4x-8x more,
 // shorter blocks) was measured on the training step and is SLOWER (polblogs B=4: 6.44 vs 5.08 ms per step;
 // B=32: 13.75 vs 12.59): every wave then stages its own weight tile.
-#ifndef EH_PIPE_MAX_BLOCKS
-#define EH_PIPE_MAX_BLOCKS 1024     // up to ~4 blocks per CU the pipelined body wins, beyond that occupancy does
-#endif
 struct eh_gemm_cfg { int nacc, gx, split, per; };
 static eh_gemm_cfg eh_gemm_config(const eh_gemm_desc& d) {
     const int64_t tiles = d.tile_row0 ? d.num_tiles : (d.M + 31) / 32;
@@ -280,15 +191,10 @@ int eh_launch_gemm(const eh_gemm_desc& d, hipStream_t stream) {
             EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm_packed<1>, dim3(gx, split), dim3(256), 0, stream, d, per));
     } else {
         const eh_gemm_cfg c = eh_gemm_config(d);
-        const bool pipe = (int64_t)c.gx * c.split <= EH_PIPE_MAX_BLOCKS;
-        if (c.nacc == 2 && pipe)
-            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL((k_gemm<2, true>), dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
-        else if (c.nacc == 2)
-            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL((k_gemm<2, false>), dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
-        else if (pipe)
-            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL((k_gemm<1, true>), dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
+        if (c.nacc == 2)
+            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<2>, dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
         else
-            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL((k_gemm<1, false>), dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
+            EH_PROF(d.prof_id, stream, hipLaunchKernelGGL(k_gemm<1>, dim3(c.gx, c.split), dim3(256), 0, stream, d, c.per));
     }
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
@@ -318,12 +224,7 @@ int eh_launch_gemm_group(const eh_gemm_desc* ds, int n, hipStream_t stream) {
         ++m;
     }
     if (m == 0) return EDGEHIP_OK;
-    int64_t blocks = 0;
-    for (int i = 0; i < m; ++i) blocks += (int64_t)g.gx[i] * g.split[i];
-    if (blocks <= EH_PIPE_MAX_BLOCKS)
-        EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL((k_gemm_group<2, true>), dim3(mx, my, m), dim3(256), 0, stream, g));
-    else
-        EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL((k_gemm_group<2, false>), dim3(mx, my, m), dim3(256), 0, stream, g));
+    EH_PROF(ds[0].prof_id, stream, hipLaunchKernelGGL(k_gemm_group<2>, dim3(mx, my, m), dim3(256), 0, stream, g));
     if (hipGetLastError() != hipSuccess) return EDGEHIP_ERR_LAUNCH;
     return EDGEHIP_OK;
 }
