@@ -37,12 +37,6 @@ def main():
     from edgehip import synth
     res = {'note': 'one MI355X, synthetic graphs of the published shapes, random-init TGNN_degree_guided (dim 64, heads '
                    '8/8/8/8/1); not bench.py lines (BASELINE quotes its metric on polblogs)'}
-    n, e = synth.cora_like(0)
-    res['cora_T512'] = sample_rate(n, e, 64, 512)
-    n, e = synth.homo_sapiens_like(0)
-    res['homo_sapiens_T512'] = sample_rate(n, e, 32, 512)
-    n, e = synth.sbm_graph(20, 1000, 0.02, 5e-4, 0)
-    res['sbm20k_T512'] = sample_rate(n, e, 4, 512)
     # Ego: batch 8 graphs of 50..400 nodes, T = 128: training step and sampling of 64
     gs = synth.ego_like(16, seed=0)
     T = 128
@@ -64,16 +58,20 @@ def main():
                                 device='cuda', degree_dtype=np.int64)
         opt = edgehip.make_optimizer(model)
         state = {}
-        for _ in range(3):
+        for _ in range(5):
             edgehip.train_step(model, tb, opt, clip_value=1.0, state=state)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        K = 20 if reps == 1 else 5
-        for _ in range(K):
+        # per-step times (t, hence the number of active pairs and the sizes torch allocates, differs from step to
+        # step: the first steps at a new size pay the caching allocator); median and mean are both kept
+        ts = []
+        for _ in range(20 if reps == 1 else 12):
+            t0 = time.perf_counter()
             edgehip.train_step(model, tb, opt, clip_value=1.0, state=state)
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / K
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        el = float(np.median(ts))
         res[name] = {'graphs_per_step': len(sel), 'nodes_per_step': int(sum(n for n, _ in sel)), 'ms_per_step': 1e3 * el,
+                     'ms_per_step_mean': 1e3 * float(np.mean(ts)), 'ms_per_step_max': 1e3 * float(np.max(ts)),
                      'graphs_per_s': len(sel) / el}
         print(f'  {name}: {1e3 * el:.2f} ms', flush=True)
     model.eval()
@@ -86,6 +84,14 @@ def main():
     el = time.perf_counter() - t0
     res['ego_T128_sample64'] = {'s_per_pass': el, 'graphs_per_s': 64 / el,
                                 'mean_edges_per_sampled_graph': int(out._slice_dict['edge_index'][-1].item()) / 64}
+    torch.cuda.empty_cache()
+    if os.environ.get('PROBE_ONLY', '') != 'ego':
+        n, e = synth.cora_like(0)
+        res['cora_T512'] = sample_rate(n, e, 64, 512)
+        n, e = synth.homo_sapiens_like(0)
+        res['homo_sapiens_T512'] = sample_rate(n, e, 32, 512)
+        n, e = synth.sbm_graph(20, 1000, 0.02, 5e-4, 0)
+        res['sbm20k_T512'] = sample_rate(n, e, 4, 512)
     s = json.dumps(res)
     print(s)
     if len(sys.argv) > 1:
