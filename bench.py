@@ -77,7 +77,10 @@ def launch_ranks(n):
         except subprocess.TimeoutExpired:
             p.kill()                       # this exact child
         rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+    # stdout carries the ONE JSON line; whatever else a library printed there (gloo's connection notice in a rehearsal)
+    # goes to stderr
+    for line in out.decode().splitlines():
+        (sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr).write(line + '\n')
     sys.stdout.flush()
     return rc
 
