@@ -856,6 +856,85 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
     }
 }
 
+// The same walk with the neighbour rows passed through LDS.  In eh_walk_list every lane gathers its own 32 bytes of
+// a neighbour row, and the HEADS groups of a slot gather the SAME bytes: a row of 256 B costs the address unit (TA,
+// 64 B per clock and CU) 2 KB worth of lanes, 32 cycles per visit against ~76 vector-ALU cycles per visit per SIMD -
+// with all four SIMDs walking the TA is the bound (PMC: TA busy 85 % of k_attn_heavy, 59 % of k_layer).  Here ONE
+// load instruction brings four whole rows (lane = 16-byte piece), the rows go to a wave-private LDS tile and the
+// lanes read their channels from there (identical addresses broadcast): 4 TA cycles per visit.  LDS operations of a
+// wave execute in order, so the tile needs no second buffer: the reads of step s are issued before the write of
+// step s + 1.  Pipeline: offsets three steps ahead, global loads two steps ahead, LDS reads one step ahead.
+#define EH_SGP 68                                  // row pitch of the staging tile (floats)
+template <int HEADS>
+__device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
+                                                  float* __restrict__ stage /* [UN][EH_SGP] of this wave */,
+                                                  const f32x2 (&q)[EH_CPL / 2], int lane, f32x2 (&acc)[EH_CPL / 2],
+                                                  float& m, float& lsum) {
+    constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
+    constexpr int NLD = UN / 4;                    // load instructions per step: four 256-byte rows each
+    static_assert(UN % 4 == 0 && EH_CPL == 8, "four rows per load instruction, two 16-byte reads per lane and visit");
+    const int grp = lane / EH_LG, c = lane % EH_LG;
+    const int slot = grp / HEADS;
+    const int nsteps = (nvis + UN - 1) / UN;
+    if (nsteps == 0) return;
+    const int lastg = nsteps - 1;
+    const int lrow = lane >> 4, lpart = lane & 15;
+    auto offs = [&](int gs, uint32_t (&o)[NLD]) {
+        gs = gs < lastg ? gs : lastg;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) o[i] = list[gs * UN + 4 * i + lrow];
+    };
+    auto gload = [&](const uint32_t (&o)[NLD], f32x4 (&g)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            g[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(hsrc) + (o[i] + (uint32_t)lpart * 16u));
+    };
+    auto swrite = [&](const f32x4 (&g)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = g[i];
+        __builtin_amdgcn_wave_barrier();           // the reads below are other lanes' writes: keep the program order
+    };
+    auto sread = [&](eh_xr (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) eh_load_cpl(x[u].p, stage + (u * NSLOT + slot) * EH_SGP + c * EH_CPL);
+        __builtin_amdgcn_wave_barrier();
+    };
+    uint32_t o[NLD];
+    f32x4 g1[NLD], g2[NLD];                        // rows of steps s + 1 and s + 2 (a load instruction is 4 registers:
+    eh_xr xa[U], xb[U];                            // two steps of global latency cost nothing)
+    offs(0, o);
+    gload(o, g1);                                  // step 0
+    offs(1, o);
+    gload(o, g2);                                  // step 1
+    offs(2, o);
+    swrite(g1);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
+    gload(o, g2);                                  // step 2
+    offs(3, o);
+    sread(xa);                                     // step 0
+    auto advance = [&](int gs, eh_xr (&xn)[U]) {   // on entry: g1 = rows of step gs + 1, g2 = step gs + 2 (in flight)
+        swrite(g1);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
+        gload(o, g2);                              // step gs + 3
+        offs(gs + 4, o);
+        sread(xn);                                 // step gs + 1
+    };
+#pragma unroll 1
+    for (int gs = 0; gs < nsteps; gs += 2) {
+        advance(gs, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        eh_walk_step<HEADS>(q, xa, nvis - gs * UN, slot, acc, m, lsum);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gs + 1 >= nsteps) break;
+        advance(gs + 1, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        eh_walk_step<HEADS>(q, xb, nvis - (gs + 1) * UN, slot, acc, m, lsum);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // merge the online-softmax states of the slots (all lanes end with the merged state)
 template <int HEADS>
 __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
@@ -892,6 +971,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
 #define EH_HCHUNK 64                   // bit-row words decoded per chunk (<= 64: one word per lane)
 #endif
     __shared__ uint32_t list[32 * EH_HCHUNK + 16];  // a chunk holds at most 32 * EH_HCHUNK neighbours (+ step padding)
+    __shared__ __attribute__((aligned(16))) float stage[UN * EH_SGP];      // rows of the step in flight (eh_walk_list_staged)
     const int lane = threadIdx.x;
     const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS, head = grp % HEADS;
@@ -953,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             while (w) { list[pos++] = (jb + (uint32_t)__ffs((int)w) - 1u) * 256u; w &= w - 1; }
             if (lane < UN) list[total + lane] = (uint32_t)node * 256u;   // filler visits of the last step (masked)
             EH_LDS_SYNC();
-            eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, lsum);
+            eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, lsum);
             EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
         }
         eh_merge_slots<HEADS>(acc, m, lsum);
