@@ -716,9 +716,6 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
 #define EH_CPL 8
 #endif
 #define EH_LG (64 / EH_CPL)          // lanes per (slot, head) group
-#ifndef EH_PF
-#define EH_PF 2                      // register sets of the fused kernel's walk (prefetch distance EH_PF-1 steps)
-#endif
 template <int HEADS>
 struct eh_walk_cfg {
     static constexpr int NSLOT = EH_CPL / HEADS;
@@ -1320,14 +1317,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             int krow = 0;                               // tile row of target k
             // the row offsets of a step are read from the LDS list one step before its gathers are issued
             // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
-            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
-            };
-            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
-            };
             auto compute = [&](const eh_xr (&x)[U]) {
                 if (st == nst) {                         // next target with work
                     do {
@@ -1356,31 +1345,57 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #else
             if (total_steps > 0) {
 #endif
-                // EH_PF register sets: the gathers run EH_PF-1 steps ahead of their use.  One step of
-                // compute (~400 issue cycles) does not cover a loaded L2 round trip, and a wave has only
-                // one partner on its SIMD (2 blocks per CU), so the walk was latency-bound at depth 2.
-                eh_xr xs[EH_PF][U];
-                uint32_t on[U];
+                // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
+                // load instruction per four rows instead of eight per-lane gathers of the same bytes; the address
+                // unit was busy 59 % of this kernel).  The tile lives in the h tile's LDS (hp), which phase A has
+                // finished with and which is loaded again before phase C.  Offsets run three steps ahead, global
+                // loads two, LDS reads one; steps past the end are skipped by predication (their clamped fetches
+                // are hits) so that the loop has ONE exit.
+                constexpr int NLD = UN / 4;
+                float* stage = hp + wave * (UN * EH_SGP);
+                const int lrow = lane >> 4, lpart = lane & 15;
                 const int lastg = total_steps - 1;
+                auto goffs = [&](int gs, uint32_t (&o)[NLD]) {
+                    gs = gs < lastg ? gs : lastg;
 #pragma unroll
-                for (int b = 0; b < EH_PF - 1; ++b) {
-                    offs_of(b < lastg ? b : lastg, on);
-                    issue(on, xs[b]);
-                    __builtin_amdgcn_sched_barrier(0);     // issue order = consumption order (vmcnt counts in order)
-                }
-                offs_of(EH_PF - 1 < lastg ? EH_PF - 1 : lastg, on);
-                // ONE loop exit: with an exit inside the unrolled body the backend funnels it through the
-                // latch and then drains the whole load queue at the loop header (s_waitcnt vmcnt(1)).  The
-                // steps past the end are skipped by predication instead; their (clamped) fetches are hits.
+                    for (int i = 0; i < NLD; ++i) o[i] = flat[gs * UN + 4 * i + lrow];
+                };
+                auto gload = [&](const uint32_t (&o)[NLD], f32x4 (&g)[NLD]) {
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i)
+                        g[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.hprev) + (o[i] + (uint32_t)lpart * 16u));
+                };
+                uint32_t o[NLD];
+                f32x4 g1[NLD], g2[NLD];
+                eh_xr xa[U], xb[U];
+                auto advance = [&](int gs, eh_xr (&xn)[U]) {   // g1 = rows of step gs + 1, g2 = step gs + 2 (in flight)
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = g1[i];
+                    __builtin_amdgcn_wave_barrier();           // the reads below are other lanes' writes: program order
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
+                    gload(o, g2);                              // step gs + 3
+                    goffs(gs + 4, o);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) eh_load_cpl(xn[u].p, stage + (u * NSLOT + slot) * EH_SGP + wc * EH_CPL);
+                    __builtin_amdgcn_wave_barrier();
+                };
+                goffs(0, o);
+                gload(o, g1);                                  // step 0
+                goffs(1, o);
+                gload(o, g2);                                  // step 1
+                goffs(2, o);
+                advance(-1, xa);                               // tile <- step 0, loads step 2, reads step 0
 #pragma unroll 1
-                for (int gs = 0; gs < total_steps; gs += EH_PF) {
-#pragma unroll
-                    for (int b = 0; b < EH_PF; ++b) {
-                        issue(on, xs[(b + EH_PF - 1) % EH_PF]);
-                        const int nx = gs + b + EH_PF;
-                        offs_of(nx < lastg ? nx : lastg, on);
-                        if (gs + b < total_steps) compute(xs[b]);
-                    }
+                for (int gs = 0; gs < total_steps; gs += 2) {
+                    advance(gs, xb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(xa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    advance(gs + 1, xa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gs + 1 < total_steps) compute(xb);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -1406,6 +1421,20 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             }
         }
         EH_SUB_AT(11);
+    }
+    if (anynbr) {
+        // the walk used the h tile's LDS as its staging tiles: bring the tile back (loads in flight across the barrier)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * 256;
+            h0v[it] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, i >> 4) * 64 + (i & 15) * 4);
+        }
+        EH_BLOCK_SYNC();                      // every wave is done with its staging tile
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * 256;
+            *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
+        }
     }
     EH_BLOCK_SYNC();
     EH_STAMP_AT(2);
