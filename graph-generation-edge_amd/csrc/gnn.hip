@@ -1842,9 +1842,13 @@ struct eh_pair_args {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) {
     __shared__ float hid[4][32][65];
+    __shared__ __attribute__((aligned(16))) float b0s[128];       // final_out.0 bias: read per tile, from LDS instead of 16 vector loads
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int total = a.counts->pair_tiles;
     const int B = L.num_graphs;
+    if ((int)blockIdx.x * 4 >= total) return;
+    if (threadIdx.x < 128 && !a.logits_in) b0s[threadIdx.x] = a.fb0[threadIdx.x];
+    __syncthreads();
     for (int tg = blockIdx.x; tg * 4 < total; tg += gridDim.x) {
         const int tile = tg * 4 + wave;
         const bool valid = tile < total;
@@ -1876,7 +1880,7 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
             for (int ch = 0; ch < 2; ++ch) {
                 const int ko = ch * 64 + hh * 32;
                 eh_frag fa, fb, fc, e;
-                eh_load_frag(fa, va + ko); eh_load_frag(fb, vb + ko); eh_load_frag(fc, a.fb0 + ko);
+                eh_load_frag(fa, va + ko); eh_load_frag(fb, vb + ko); eh_load_frag(fc, b0s + ko);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
