@@ -1030,7 +1030,9 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             while (w) { list[pos++] = (jb + (uint32_t)__ffs((int)w) - 1u) * 256u; w &= w - 1; }
             if (lane < UN) list[total + lane] = (uint32_t)node * 256u;   // filler visits of the last step (masked)
             EH_LDS_SYNC();
-            eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, lsum);
+            // HEADS >= 4: the head groups of a slot would gather the same bytes 4-8 times - go through LDS
+            if constexpr (HEADS >= 4) eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, lsum);
+            else eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, lsum);
             EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
         }
         eh_merge_slots<HEADS>(acc, m, lsum);
@@ -1317,6 +1319,14 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             int krow = 0;                               // tile row of target k
             // the row offsets of a step are read from the LDS list one step before its gathers are issued
             // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
+            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
+            };
+            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
+            };
             auto compute = [&](const eh_xr (&x)[U]) {
                 if (st == nst) {                         // next target with work
                     do {
@@ -1345,6 +1355,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #else
             if (total_steps > 0) {
 #endif
+                if constexpr (HEADS >= 4) {
                 // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
                 // load instruction per four rows instead of eight per-lane gathers of the same bytes; the address
                 // unit was busy 59 % of this kernel).  The tile lives in the h tile's LDS (hp), which phase A has
@@ -1397,6 +1408,34 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                     if (gs + 1 < total_steps) compute(xb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                } else {
+                // HEADS <= 2: a load instruction already brings 4-8 different rows (one per slot): gather directly,
+                // two register sets, the gathers one step ahead of their use
+                constexpr int EH_PF = 2;
+                eh_xr xs[EH_PF][U];
+                uint32_t on[U];
+                const int lastg = total_steps - 1;
+#pragma unroll
+                for (int b = 0; b < EH_PF - 1; ++b) {
+                    offs_of(b < lastg ? b : lastg, on);
+                    issue(on, xs[b]);
+                    __builtin_amdgcn_sched_barrier(0);     // issue order = consumption order (vmcnt counts in order)
+                }
+                offs_of(EH_PF - 1 < lastg ? EH_PF - 1 : lastg, on);
+                // ONE loop exit: with an exit inside the unrolled body the backend funnels it through the
+                // latch and then drains the whole load queue at the loop header (s_waitcnt vmcnt(1)).  The
+                // steps past the end are skipped by predication instead; their (clamped) fetches are hits.
+#pragma unroll 1
+                for (int gs = 0; gs < total_steps; gs += EH_PF) {
+#pragma unroll
+                    for (int b = 0; b < EH_PF; ++b) {
+                        issue(on, xs[(b + EH_PF - 1) % EH_PF]);
+                        const int nx = gs + b + EH_PF;
+                        offs_of(nx < lastg ? nx : lastg, on);
+                        if (gs + b < total_steps) compute(xs[b]);
+                    }
+                }
+                }
             }
         }
         EH_SUB_AT(10);
@@ -1422,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
         EH_SUB_AT(11);
     }
-    if (anynbr) {
+    if (HEADS >= 4 && anynbr) {
         // the walk used the h tile's LDS as its staging tiles: bring the tile back (loads in flight across the barrier)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
