@@ -1880,13 +1880,22 @@ struct eh_pair_args {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) {
-    __shared__ float hid[4][32][65];
-    __shared__ __attribute__((aligned(16))) float b0s[128];       // final_out.0 bias: read per tile, from LDS instead of 16 vector loads
+    // The address unit bounds this kernel when the active sets are large (68 % TA busy at 684 k pairs per step): per
+    // 32-pair tile a wave issued 32 loads for its two node rows, 16 for the bias and 48 for the four weight fragments,
+    // the same 48 KB of weights for every tile.  The block now holds the fragments and the bias in LDS (one copy per
+    // block and launch), and the hidden tile passes through LDS in two halves of 32 columns, which keeps two blocks per CU.
+    __shared__ float hid[4][32][33];
+    __shared__ __attribute__((aligned(16))) float b0s[128];       // final_out.0 bias
+    __shared__ __attribute__((aligned(16))) float wlds[4 * EH_PK_TILE];   // final_out.2 fragments (nt, ch) = tile nt * 2 + ch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int total = a.counts->pair_tiles;
     const int B = L.num_graphs;
     if ((int)blockIdx.x * 4 >= total) return;
-    if (threadIdx.x < 128 && !a.logits_in) b0s[threadIdx.x] = a.fb0[threadIdx.x];
+    if (!a.logits_in) {
+        if (threadIdx.x < 128) b0s[threadIdx.x] = a.fb0[threadIdx.x];
+        for (int i = threadIdx.x; i < EH_PK_TILE; i += 256)
+            reinterpret_cast<f32x4*>(wlds)[i] = reinterpret_cast<const f32x4*>(a.pfw2)[i];
+    }
     __syncthreads();
     for (int tg = blockIdx.x; tg * 4 < total; tg += gridDim.x) {
         const int tile = tg * 4 + wave;
@@ -1911,6 +1920,7 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
             if (k >= A) k = A - 1;
             eh_pair_decode(k, K, p, q);
         }
+        f32x16 hacc0 = eh_zero16(), hacc1 = eh_zero16();      // hidden tile of this wave (columns r and 32 + r)
         if (valid && !a.logits_in) {
             const float* va = a.node_repr + (size_t)(kbase + p) * 128;
             const float* vb = a.node_repr + (size_t)(kbase + q) * 128;
@@ -1926,35 +1936,43 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
                     for (int c = 0; c < 4; ++c) e.v[i][c] = eh_silu_fast(fa.v[i][c] + fb.v[i][c] + fc.v[i][c]);
                 eh_pfrag e3, w;
                 eh_to_pfrag(e3, e);
-                eh_load_frag_packed(w, a.pfw2, 2, 0, ch, lane); eh_mma64(acc0, e3, w);
-                eh_load_frag_packed(w, a.pfw2, 2, 1, ch, lane); eh_mma64(acc1, e3, w);
+                eh_load_frag_packed(w, wlds, 2, 0, ch, lane); eh_mma64(acc0, e3, w);
+                eh_load_frag_packed(w, wlds, 2, 1, ch, lane); eh_mma64(acc1, e3, w);
             }
             const float b20 = a.fb2[r], b21 = a.fb2[32 + r];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                int rr = eh_crow(i, lane);
-                hid[wave][rr][r] = eh_silu_fast(acc0[i] + b20);
-                hid[wave][rr][32 + r] = eh_silu_fast(acc1[i] + b21);
+                acc0[i] = eh_silu_fast(acc0[i] + b20);
+                acc1[i] = eh_silu_fast(acc1[i] + b21);
             }
+            hacc0 = acc0; hacc1 = acc1;
         }
-        __syncthreads();
-        // lane = (pair pr, class c)
+        // lane = (pair pr, class c); the 64-term dot with final_out.4 runs over the two column halves in turn, one
+        // running sum in the original order
         const int pr = lane >> 1, c = lane & 1;
         const int64_t k = k0 + pr;
         const bool live = valid && k < A;
         float logit = 0.f;
-        if (live) {
-            if (a.logits_in) {
-                logit = a.logits_in[(abase + k) * 2 + c];
-            } else {
-                const float* w4 = a.fw4 + c * 64;
-                float s = a.fb4[c];
+        if (a.logits_in) {
+            if (live) logit = a.logits_in[(abase + k) * 2 + c];
+        } else {
+            const float* w4 = a.fw4 + c * 64;
+            float s = a.fb4[c];
+#pragma unroll
+            for (int half2 = 0; half2 < 2; ++half2) {
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hid[wave][eh_crow(i, lane)][r] = half2 ? hacc1[i] : hacc0[i];
+                }
+                __syncthreads();
+                if (live) {
 #pragma unroll 8
-                for (int d = 0; d < 64; ++d) s += hid[wave][pr][d] * w4[d];
-                logit = s;
+                    for (int d = 0; d < 32; ++d) s += hid[wave][pr][d] * w4[32 * half2 + d];
+                }
+                __syncthreads();
             }
+            logit = s;
         }
-        __syncthreads();
         float other = __shfl_xor(logit, 1);
         float l0 = c == 0 ? logit : other, l1 = c == 0 ? other : logit;
         // the pair of lane pr (decoded by lane pr < 32): fetch (p,q) of pair `pr`
