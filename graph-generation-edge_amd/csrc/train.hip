@@ -1222,21 +1222,46 @@ static int tr_global_fwd(const edgehip_gnn_params* P, const tr_plan& p, int j, i
 // so they are queued on a second HIP stream behind an event of the launch that produced their dY and overlap
 // with the latency-bound chain of input-gradient products (one per device, created on first use).
 #include <mutex>
-struct tr_aux_t { hipStream_t side = nullptr; hipEvent_t ev[160]; int nev = 0; bool ok = false; };
+struct tr_aux_t { hipStream_t side = nullptr; hipEvent_t ev[160]; int nev = 0; bool ok = false; bool own = false; };
 static tr_aux_t g_tr_aux[16];
 static std::mutex g_tr_aux_mu;
+static bool tr_aux_events(tr_aux_t& a) {
+    for (; a.nev < 160; ++a.nev)
+        if (hipEventCreateWithFlags(&a.ev[a.nev], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
 static tr_aux_t* tr_aux() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lk(g_tr_aux_mu);
     tr_aux_t& a = g_tr_aux[dev];
     if (!a.ok) {
-        if (hipStreamCreateWithFlags(&a.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (a.nev = 0; a.nev < 160; ++a.nev)
-            if (hipEventCreateWithFlags(&a.ev[a.nev], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!a.side) {
+            if (hipStreamCreateWithFlags(&a.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+            a.own = true;
+        }
+        if (!tr_aux_events(a)) return nullptr;
         a.ok = true;
     }
     return &a;
+}
+// A process has few hardware queues (4 by default) and HIP deals streams to them in creation order: a caller that
+// keeps side streams of its own (the Python host: the sampler's sub-batch streams) hands one of them over, so that
+// training and sampling together do not create more streams than there are queues - two streams on one queue run
+// one after the other (measured: three-stream sampling after training in the same process 162 -> 114 graphs/s).
+extern "C" int edgehip_train_set_side_stream(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return EDGEHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_tr_aux_mu);
+    tr_aux_t& a = g_tr_aux[dev];
+    if (a.side && a.own && a.side != (hipStream_t)stream) {
+        (void)hipStreamSynchronize(a.side);
+        (void)hipStreamDestroy(a.side);
+    }
+    a.side = (hipStream_t)stream;          // NULL: the library creates its own at the next backward
+    a.own = false;
+    a.ok = false;
+    return EDGEHIP_OK;
 }
 struct tr_dw_ctx {
     hipStream_t main; tr_aux_t* aux; int used;

@@ -396,7 +396,7 @@ class BinomialDiffusionActive(nn.Module):
             dev = batch.device
             rb = self.__dict__.setdefault('_rb', {}).get(str(dev))
             if rb is None:
-                rb = self._rb[str(dev)] = (torch.cuda.Stream(device=dev), torch.empty(8, dtype=torch.int32).pin_memory(),
+                rb = self._rb[str(dev)] = (capi.side_streams(dev, 2)[1], torch.empty(8, dtype=torch.int32).pin_memory(),
                                            torch.cuda.Event())
             stream, pinned, done = rb
             stream.wait_event(after)
@@ -509,12 +509,13 @@ class BinomialDiffusionActive(nn.Module):
             cur = torch.cuda.current_stream(dev)
             # the first block stays on the caller's stream: a process has 4 hardware queues (GPU_MAX_HW_QUEUES), and a
             # stream beyond them shares a queue with another one (measured: 82.6 graphs/s with 4 side streams)
-            streams = [cur] + self._streams(dev, len(subs) - 1)
+            pool = [cur] + self._streams(dev, len(subs) - 1)      # at most 1 + capi.MAX_SIDE_STREAMS different streams
+            streams = [pool[i % len(pool)] for i in range(len(subs))]
             work = []
             # every buffer of the blocks is allocated (and zero-filled) on the current stream BEFORE the side streams
             # are ordered behind it: a fill queued later on `cur` could land on top of a block's first step
             prepared = [(_state(b)['counts'], _workspace(b, P)) for b in subs]
-            for st in streams[1:]:
+            for st in pool[1:]:
                 st.wait_stream(cur)          # also: tables / folded weights were produced on the current stream
             for b, st, (counts, ws) in zip(subs, streams, prepared):
                 with torch.cuda.stream(st):
@@ -529,16 +530,12 @@ class BinomialDiffusionActive(nn.Module):
                 if step_stats is not None:
                     capi.check(capi.lib.edgehip_prof_step_stats(Lr, pref, ws, wsn, counts, step_stats.data_ptr() + 64 * t, s),
                                'prof_step_stats')
-        for st in streams[1:]:
+        for st in set(streams[1:]) - {streams[0]} if streams else ():
             streams[0].wait_stream(st)
         return self._finish_sample(batch)
 
     def _streams(self, dev, n):
-        key = str(dev)
-        have = self.__dict__.setdefault('_side_streams', {}).setdefault(key, [])
-        while len(have) < n:
-            have.append(torch.cuda.Stream(device=dev))
-        return have[:n]
+        return capi.side_streams(dev, n)
 
     def _finish_sample(self, batch):
         edge_index, edge_slice = batch.extract_edges()

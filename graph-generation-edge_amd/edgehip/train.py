@@ -498,6 +498,7 @@ class _FusedNet(Function):
         net.fill_struct(G, address)
         gce = gce.contiguous()
         dp = ctx.dp
+        capi.use_pool_for_training(adj_t.device)
         capi.check(lib.edgehip_train_backward_dp(byref(L), byref(P), byref(G), adj_t.data_ptr(), deg_t.data_ptr(),
                                                  d0.data_ptr(), flags.data_ptr(), capi.ptr(row), capi.ptr(col), row.numel(),
                                                  ctx.cap, capi.ptr(tgt), capi.ptr(pair_graph), gce.data_ptr(),

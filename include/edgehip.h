@@ -14,9 +14,10 @@
  *     sampling loop needs no host synchronisation.
  *
  * Process state: the data path keeps none.  Two documented exceptions, both per device and created on
- * first use: (1) edgehip_train_backward* queue the weight-gradient products on a library-owned
- * non-blocking side stream joined back into `stream` before the call returns its work (csrc/train.hip
- * tr_aux; it never outlives an entry point's ordering: the caller sees one stream); (2) the measurement hooks at
+ * first use: (1) edgehip_train_backward* queue the weight-gradient products on a non-blocking side stream
+ * (library-owned unless the caller supplies one, edgehip_train_set_side_stream) joined back into `stream`
+ * before the call returns its work (csrc/train.hip tr_aux; it never outlives an entry point's ordering: the
+ * caller sees one stream); (2) the measurement hooks at
  * the end of this file (off by default).  edgehip_edge_ce_loss_static additionally owns a fixed device
  * scratch array (see there).
  *
@@ -410,6 +411,12 @@ int edgehip_train_backward(const edgehip_layout* L, const edgehip_gnn_params* P,
                            const uint32_t* adj_t, const int32_t* deg_t, const int32_t* d0, const uint8_t* flags,
                            const int64_t* row, const int64_t* col, int64_t A, const uint8_t* tgt,
                            const int32_t* pair_graph, const float* gce, void* ws, size_t ws_bytes, void* stream);
+/* The side stream of edgehip_train_backward* on the CURRENT device (see "Process state" at the top): by default the
+ * library creates one on first use.  A caller that keeps side streams of its own passes one here (NULL: back to a
+ * library-owned stream) so that the process does not hold more streams than it has hardware queues; the stream must
+ * outlive every later backward on this device.  No counterpart in the reference (single stream). */
+int edgehip_train_set_side_stream(void* stream);
+
 
 /* ---- statistics of the sampled graphs (next row after the path) ------------------------
  * replaces: the degree / triangle / assortativity part of compute_graph_statistics,
