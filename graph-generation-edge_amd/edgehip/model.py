@@ -470,10 +470,12 @@ class BinomialDiffusionActive(nn.Module):
 
     @staticmethod
     def default_parts(num_graphs):
-        """Sub-batches (= HIP streams, the caller's included) the sampler cuts a batch into: 3 once there are at
-        least 8 graphs per part (polblogs, 64 graphs, one MI355X: 1 part 105.5, 2 parts 109.8, 3 parts 111.5, 4 parts
-        111.8 graphs/s; a process has 4 hardware queues, a fifth stream shares one: 82.6)."""
-        return max(1, min(3, num_graphs // 8))
+        """Sub-batches (= HIP streams, the caller's included) the sampler cuts a batch into: two from 16 graphs on (the
+        side stream comes from the package's one pool, capi.side_streams).  polblogs on one MI355X, one box, graphs/s
+        with 1 / 2 / 3 / 4 streams: 64 graphs 135.4 / 143.2 / 141.0 / 139.0, 32 graphs - / 106.6 / 104.8 / 107.1,
+        16 graphs 65.8 / 70.2: while one block sits in its latency-bound launches the other's fused layer kernel
+        fills the chip; a third and fourth block add launches without more overlap."""
+        return 2 if num_graphs >= 16 else 1
 
     @_on_batch_device
     @torch.no_grad()

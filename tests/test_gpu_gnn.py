@@ -258,7 +258,7 @@ def test_sampler_on_sub_batch_streams_is_bit_identical(parts):
     model.sample_batch(bk, seed + 1, parts=parts)
     model.sample_batch(b1, seed + 1, parts=1)
     assert torch.equal(b1.edge_index, bk.edge_index)
-    assert model.default_parts(64) == 3 and model.default_parts(7) == 1 and model.default_parts(16) == 2
+    assert model.default_parts(64) == 2 and model.default_parts(7) == 1 and model.default_parts(16) == 2
     # new target degrees written into the same batch object: the cached blocks (which copy d0) are rebuilt
     halved = torch.div(bk.degree_i32, 2, rounding_mode='floor')
     for b in (b1, bk):
