@@ -559,6 +559,16 @@ def test_sampling_after_training_steps_uses_the_updated_weights():
     e2, s2 = generate(fresh)
     assert torch.equal(e1, e2) and torch.equal(s1, s2)
     assert e0.shape != e1.shape or not torch.equal(e0, e1)
+    # sampler blocks, the count read-back and the backward's weight-gradient stream all come from ONE small pool of
+    # side streams (streams created independently end up sharing a hardware queue)
+    from edgehip import capi
+    pool = capi._SIDE_STREAMS[torch.cuda.current_device()]
+    assert 1 <= len(pool) <= capi.MAX_SIDE_STREAMS
+    assert all(rb[0] in pool for rb in getattr(model, '_rb', {}).values())
+    assert torch.cuda.current_device() in capi._TRAIN_SIDE_SET
+    sb = H.graph_batch(graphs, with_edges=False, gid_base=4)
+    model.sample_batch(sb, seed=21, parts=6)             # more blocks than streams: blocks share streams in turn
+    assert torch.equal(sb.edge_index, e1) and len(capi._SIDE_STREAMS[torch.cuda.current_device()]) <= capi.MAX_SIDE_STREAMS
 
 
 def test_alternating_batches_share_one_model_and_arena():
