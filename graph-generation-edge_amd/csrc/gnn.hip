@@ -760,6 +760,7 @@ __device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc
 // The walk keeps its scores in the log2 domain: qt rows are multiplied by log2(e) once per target, so every
 // softmax weight is one v_exp_f32 (2^x) without the per-visit multiply of exp(x) = 2^(x log2 e).
 __device__ static inline float eh_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#define EH_REF_SLACK 32.f       // log2 units a score may exceed the softmax reference before the reference moves
 __device__ static inline void eh_scale_q_log2e(f32x2 (&q)[EH_CPL / 2]) {
     const f32x2 k = f32x2{1.4426950408889634f, 1.4426950408889634f};
 #pragma unroll
@@ -804,21 +805,29 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
-    const float resc = eh_exp2(m - mn);
+    // m is the REFERENCE of the running softmax (weights 2^(score - m)), not necessarily the maximum: it moves to the
+    // maximum only when a score of some lane leaves it more than EH_REF_SLACK behind (wave-uniform branch: the first
+    // step of a row, then rarely).  Weights stay below 2^EH_REF_SLACK, relative precision is that of fp32 either
+    // way, and a step that keeps its reference costs neither the rescale factor (a quarter-rate exp) nor the
+    // multiplies of acc and lsum.
+    if (__any(mn > m + EH_REF_SLACK)) {
+        const float resc = eh_exp2(m - mn);
+        lsum *= resc;
+        const f32x2 r2 = f32x2{resc, resc};
+#pragma unroll
+        for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
+        m = mn;
+    }
     float ps = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { sc[u] = eh_exp2(sc[u] - mn); ps += sc[u]; }
-    lsum = lsum * resc + ps;
-    const f32x2 r2 = f32x2{resc, resc};
-#pragma unroll
-    for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
+    for (int u = 0; u < U; ++u) { sc[u] = eh_exp2(sc[u] - m); ps += sc[u]; }
+    lsum += ps;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const f32x2 p2 = f32x2{sc[u], sc[u]};
 #pragma unroll
         for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = __builtin_elementwise_fma(p2, x[u].p[d], acc[d]);
     }
-    m = mn;
 }
 
 template <int HEADS>
@@ -862,6 +871,9 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
 // wave execute in order, so the tile needs no second buffer: the reads of step s are issued before the write of
 // step s + 1.  Pipeline: offsets three steps ahead, global loads two steps ahead, LDS reads one step ahead.
 #define EH_SGP 68                                  // row pitch of the staging tile (floats)
+#ifndef EH_WALK_DEPTH
+#define EH_WALK_DEPTH 2                            // even (the two register sets of the visits alternate); 4, 6, 8 measured: no change
+#endif
 template <int HEADS>
 __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
                                                   float* __restrict__ stage /* [UN][EH_SGP] of this wave */,
@@ -869,7 +881,7 @@ __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ l
                                                   float& m, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
     constexpr int NLD = UN / 4;                    // load instructions per step: four 256-byte rows each
-    static_assert(UN % 4 == 0 && EH_CPL == 8, "four rows per load instruction, two 16-byte reads per lane and visit");
+    static_assert(UN % 4 == 0, "four rows per load instruction");
     const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS;
     const int nsteps = (nvis + UN - 1) / UN;
@@ -896,39 +908,30 @@ __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ l
         for (int u = 0; u < U; ++u) eh_load_cpl(x[u].p, stage + (u * NSLOT + slot) * EH_SGP + c * EH_CPL);
         __builtin_amdgcn_wave_barrier();
     };
+    constexpr int D = EH_WALK_DEPTH;               // steps of global loads in flight (a load instruction is 4 registers)
     uint32_t o[NLD];
-    f32x4 g1[NLD], g2[NLD];                        // rows of steps s + 1 and s + 2 (a load instruction is 4 registers:
-    eh_xr xa[U], xb[U];                            // two steps of global latency cost nothing)
-    offs(0, o);
-    gload(o, g1);                                  // step 0
-    offs(1, o);
-    gload(o, g2);                                  // step 1
-    offs(2, o);
-    swrite(g1);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
-    gload(o, g2);                                  // step 2
-    offs(3, o);
-    sread(xa);                                     // step 0
-    auto advance = [&](int gs, eh_xr (&xn)[U]) {   // on entry: g1 = rows of step gs + 1, g2 = step gs + 2 (in flight)
-        swrite(g1);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
-        gload(o, g2);                              // step gs + 3
-        offs(gs + 4, o);
-        sread(xn);                                 // step gs + 1
+    f32x4 g[D][NLD];                               // ring: at step s, g[(s + k) % D] holds the rows of step s + k, k = 1 .. D
+    eh_xr x[2][U];
+    auto advance = [&](f32x4 (&gr)[NLD], int nextoffs, eh_xr (&xn)[U]) {   // gr: rows of the step after the current one
+        swrite(gr);
+        gload(o, gr);                              // D steps further on
+        offs(nextoffs, o);
+        sread(xn);
     };
+#pragma unroll
+    for (int j = 0; j < D; ++j) { offs(j, o); gload(o, g[j]); }
+    offs(D, o);
+    advance(g[0], D + 1, x[0]);                    // tile <- step 0, loads step D, reads step 0
 #pragma unroll 1
-    for (int gs = 0; gs < nsteps; gs += 2) {
-        advance(gs, xb);
-        __builtin_amdgcn_sched_barrier(0);
-        eh_walk_step<HEADS>(q, xa, nvis - gs * UN, slot, acc, m, lsum);
-        __builtin_amdgcn_sched_barrier(0);
-        if (gs + 1 >= nsteps) break;
-        advance(gs + 1, xa);
-        __builtin_amdgcn_sched_barrier(0);
-        eh_walk_step<HEADS>(q, xb, nvis - (gs + 1) * UN, slot, acc, m, lsum);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int gs = 0; gs < nsteps; gs += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            // steps past the end are skipped by predication (their clamped fetches are hits): ONE loop exit
+            advance(g[(j + 1) % D], gs + j + 2 + D, x[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gs + j < nsteps) eh_walk_step<HEADS>(q, x[j & 1], nvis - (gs + j) * UN, slot, acc, m, lsum);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -986,20 +989,21 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
     const int first = nlong > jb ? (nlong - jb + nloc - 1) / nloc : 0;   // long rows this block takes
     int gcur = g0, gbase = 0;
     for (int round = 0;; ++round) {
-        int idx;
+        int idx, g;                                                  // the list position names the graph: no look-up by node
         if (round < first) {
             const int li = jb + round * nloc;
             while (li >= gbase + clong[gcur]) { gbase += clong[gcur]; ++gcur; }
+            g = gcur;
             idx = L.node_ptr[gcur + 1] - 1 - (li - gbase);
             if (round + 1 == first) { gcur = g0; gbase = 0; }       // the cursor starts over for the second list
         } else {
             const int li = jb + (round - first) * nloc;
             if (li >= total) break;
             while (li >= gbase + counter[gcur]) { gbase += counter[gcur]; ++gcur; }
+            g = gcur;
             idx = L.node_ptr[gcur] + (li - gbase);
         }
         const int node = heavy_pg[idx], cidx = idx;
-        const int g = L.node_graph[node];
         const int node0 = L.node_ptr[g];
         const int stride = L.adj_stride[g];
         const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
@@ -1376,37 +1380,33 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                     for (int i = 0; i < NLD; ++i)
                         g[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.hprev) + (o[i] + (uint32_t)lpart * 16u));
                 };
+                constexpr int D = EH_WALK_DEPTH;
                 uint32_t o[NLD];
-                f32x4 g1[NLD], g2[NLD];
-                eh_xr xa[U], xb[U];
-                auto advance = [&](int gs, eh_xr (&xn)[U]) {   // g1 = rows of step gs + 1, g2 = step gs + 2 (in flight)
+                f32x4 g[D][NLD];                               // ring: rows of the next D steps, in flight
+                eh_xr x[2][U];
+                auto advance = [&](f32x4 (&gr)[NLD], int nextoffs, eh_xr (&xn)[U]) {   // gr: rows of the step after the current one
 #pragma unroll
-                    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = g1[i];
+                    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = gr[i];
                     __builtin_amdgcn_wave_barrier();           // the reads below are other lanes' writes: program order
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) g1[i] = g2[i];
-                    gload(o, g2);                              // step gs + 3
-                    goffs(gs + 4, o);
+                    gload(o, gr);                              // D steps further on
+                    goffs(nextoffs, o);
 #pragma unroll
                     for (int u = 0; u < U; ++u) eh_load_cpl(xn[u].p, stage + (u * NSLOT + slot) * EH_SGP + wc * EH_CPL);
                     __builtin_amdgcn_wave_barrier();
                 };
-                goffs(0, o);
-                gload(o, g1);                                  // step 0
-                goffs(1, o);
-                gload(o, g2);                                  // step 1
-                goffs(2, o);
-                advance(-1, xa);                               // tile <- step 0, loads step 2, reads step 0
+#pragma unroll
+                for (int j = 0; j < D; ++j) { goffs(j, o); gload(o, g[j]); }
+                goffs(D, o);
+                advance(g[0], D + 1, x[0]);                    // tile <- step 0, loads step D, reads step 0
 #pragma unroll 1
-                for (int gs = 0; gs < total_steps; gs += 2) {
-                    advance(gs, xb);
-                    __builtin_amdgcn_sched_barrier(0);
-                    compute(xa);
-                    __builtin_amdgcn_sched_barrier(0);
-                    advance(gs + 1, xa);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (gs + 1 < total_steps) compute(xb);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int gs = 0; gs < total_steps; gs += D) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        advance(g[(j + 1) % D], gs + j + 2 + D, x[(j + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (gs + j < total_steps) compute(x[j & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 } else {
                 // HEADS <= 2: a load instruction already brings 4-8 different rows (one per slot): gather directly,
@@ -1446,16 +1446,21 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             const int hslot = __shfl(hs8, grp);
             const int trow = __shfl(trow8, grp);          // outside the branch: the source lanes must be active
             if (tdeg == 0) {
+                // every load of the row first, then the stores: written head by head, the compiler waits for
+                // each pair of heads before it requests the next (four exposed round trips per heavy row)
                 float* zrow = qz + trow * QP + c * 8;
+                f32x4 zv[2 * HEADS];
+#pragma unroll
+                for (int h = 0; h < 2 * HEADS; ++h) zv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (hslot >= 0) {
+                    const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + c * 8);
+#pragma unroll
+                    for (int h = 0; h < HEADS; ++h) { zv[2 * h] = zp[h * 16]; zv[2 * h + 1] = zp[h * 16 + 1]; }
+                }
 #pragma unroll
                 for (int h = 0; h < HEADS; ++h) {
-                    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-                    if (hslot >= 0) {
-                        const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + h * 64 + c * 8);
-                        o0 = zp[0]; o1 = zp[1];
-                    }
-                    *reinterpret_cast<f32x4*>(zrow + h * 64) = o0;
-                    *reinterpret_cast<f32x4*>(zrow + h * 64 + 4) = o1;
+                    *reinterpret_cast<f32x4*>(zrow + h * 64) = zv[2 * h];
+                    *reinterpret_cast<f32x4*>(zrow + h * 64 + 4) = zv[2 * h + 1];
                 }
             }
         }
