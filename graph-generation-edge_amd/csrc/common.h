@@ -12,6 +12,13 @@
 static inline hipStream_t eh_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int eh_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// riders of the selection launch inside the fused reverse step (state.hip: eh_active_select_step)
+struct eh_select_extra { int32_t* t_out; int32_t t; int32_t* clear; int clear_n; };
+int eh_active_select_step(const edgehip_layout* L, const int32_t* d0, const int32_t* deg, int32_t t, int32_t* t_out,
+                          const float* post_table, int32_t nmax, const float* uniforms, const edgehip_rng* rng,
+                          const float* gumbel_lut, uint8_t* flags, int32_t* act_nodes, int32_t* act_count,
+                          int32_t* clear, int clear_n, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based.  One call gives 4 x 32 random bits.
 // ---------------------------------------------------------------------------------------------

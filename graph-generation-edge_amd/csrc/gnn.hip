@@ -1753,7 +1753,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
                                const uint32_t* adj, const int32_t* deg, const int32_t* d0, const int32_t* t_graph,
                                int t_shared, const uint8_t* flags, const int32_t* act_nodes, const int32_t* kptr,
                                const edgehip_counts* counts, float* node_repr, float* h_out, const eh_ws& w,
-                               hipStream_t s) {
+                               hipStream_t s, bool counters_cleared = false) {
     eh_fold_map fm = eh_make_fold_map(P);
     const int B = L->num_graphs, Nn = L->num_nodes, NT = L->num_tiles;
     if (B == 0 || Nn == 0) return EDGEHIP_OK;
@@ -1764,7 +1764,8 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);       // heavy and long rows per graph
+    // heavy and long rows per graph start at zero (the fused reverse step clears them in its selection launch)
+    if (!counters_cleared) (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);
     {
         eh_prep_args pa = {};
         pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
@@ -2202,11 +2203,6 @@ extern "C" int edgehip_edge_ce_loss_static(const edgehip_layout* L, const edgehi
 // --------------------------------------------------------------------------------------------
 // one reverse step (p_sample) for the whole batch, no host sync
 // --------------------------------------------------------------------------------------------
-__global__ void k_fill_i32(int32_t* p, int n, int v) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 extern "C" int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
                                    uint32_t* adj, const int32_t* d0, int32_t t, const float* post_table, int32_t nmax,
                                    const float* u_node, const float* u_pair, const edgehip_rng* rng,
@@ -2220,16 +2216,16 @@ extern "C" int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_pa
     if (ws_bytes < w.bytes) return EDGEHIP_ERR_WORKSPACE;
     if (L->num_graphs == 0 || L->num_nodes == 0) return EDGEHIP_OK;
     hipStream_t s = eh_stream(stream);
-    hipLaunchKernelGGL(k_fill_i32, dim3((L->num_graphs + 255) / 256), dim3(256), 0, s, w.t_graph, L->num_graphs, t);
     rc = edgehip_degree_from_adj(L, adj, w.deg, stream);
     if (rc) return rc;
-    rc = edgehip_active_select_sample(L, d0, w.deg, w.t_graph, post_table, nmax, u_node, rng, gumbel_lut, w.flags,
-                                      w.act_nodes, w.act_count, stream);
+    // the selection launch also writes t for every graph and clears the heavy-row counters of the forward pass
+    rc = eh_active_select_step(L, d0, w.deg, t, w.t_graph, post_table, nmax, u_node, rng, gumbel_lut, w.flags,
+                               w.act_nodes, w.act_count, w.heavy_count, (int)EH_HC_INTS(L->num_graphs), s);
     if (rc) return rc;
     rc = edgehip_active_offsets(L, w.act_count, w.kptr, w.aptr, w.tptr, counts, stream);
     if (rc) return rc;
     rc = eh_gnn_forward_impl(L, P, folded, adj, w.deg, d0, w.t_graph, 1, w.flags, w.act_nodes, w.kptr, counts,
-                             w.node_repr, nullptr, w, s);
+                             w.node_repr, nullptr, w, s, true);
     if (rc) return rc;
     return edgehip_edge_resample(L, P, folded, w.node_repr, w.act_nodes, w.kptr, w.aptr, w.tptr, counts, nullptr, 0,
                                  u_pair, rng, t, gumbel_lut, adj, nullptr, nullptr, 0, stream);

@@ -52,13 +52,18 @@ __global__ __launch_bounds__(256) void k_select(edgehip_layout L, const int32_t*
                                                 const float* __restrict__ post, int nmax,
                                                 const float* __restrict__ uniforms, edgehip_rng rng, int use_rng,
                                                 const float* __restrict__ lut, uint8_t* __restrict__ flags,
-                                                int32_t* __restrict__ act_nodes, int32_t* __restrict__ act_count) {
+                                                int32_t* __restrict__ act_nodes, int32_t* __restrict__ act_count,
+                                                eh_select_extra x) {
     __shared__ int wave_cnt[4];
     __shared__ int running;
     int b = blockIdx.x;
     int node0 = L.node_ptr[b], n = L.node_ptr[b + 1] - node0;
     int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int t = (MODE == 0) ? t_graph[b] : 0;
+    int t = (MODE == 0) ? (x.t_out ? x.t : t_graph[b]) : 0;
+    // the fused reverse step: its two small fills ride along (one t for every graph; counters of the launches that
+    // follow start at zero) instead of being launches of their own
+    if (x.t_out && tid == 0) x.t_out[b] = x.t;
+    if (x.clear) for (int i = b * 256 + tid; i < x.clear_n; i += gridDim.x * 256) x.clear[i] = 0;
     if (tid == 0) running = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 256) {
@@ -107,7 +112,24 @@ extern "C" int edgehip_active_select_sample(const edgehip_layout* L, const int32
     if (L->num_graphs == 0) return EDGEHIP_OK;
     edgehip_rng r = rng ? *rng : edgehip_rng{0};
     EH_PROF(EH_K_SELECT, eh_stream(stream), hipLaunchKernelGGL(k_select<0>, dim3(L->num_graphs), dim3(256), 0, eh_stream(stream), *L, d0, deg, t_graph,
-                       post_table, nmax, uniforms, r, uniforms ? 0 : 1, gumbel_lut, flags, act_nodes, act_count));
+                       post_table, nmax, uniforms, r, uniforms ? 0 : 1, gumbel_lut, flags, act_nodes, act_count, eh_select_extra{}));
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
+// the same selection inside edgehip_sample_step: one t for all graphs (written to t_out for the kernels that follow)
+// and `clear_n` ints at `clear` set to zero by the same launch
+int eh_active_select_step(const edgehip_layout* L, const int32_t* d0, const int32_t* deg, int32_t t, int32_t* t_out,
+                          const float* post_table, int32_t nmax, const float* uniforms, const edgehip_rng* rng,
+                          const float* gumbel_lut, uint8_t* flags, int32_t* act_nodes, int32_t* act_count,
+                          int32_t* clear, int clear_n, hipStream_t s) {
+    EH_CHECK_ARG(L && d0 && deg && t_out && post_table && flags && act_nodes && act_count && nmax >= 0);
+    EH_CHECK_ARG(uniforms || rng);
+    if (L->num_graphs == 0) return EDGEHIP_OK;
+    edgehip_rng r = rng ? *rng : edgehip_rng{0};
+    eh_select_extra x = {t_out, t, clear, clear_n};
+    EH_PROF(EH_K_SELECT, s, hipLaunchKernelGGL(k_select<0>, dim3(L->num_graphs), dim3(256), 0, s, *L, d0, deg, (const int32_t*)nullptr,
+                       post_table, nmax, uniforms, r, uniforms ? 0 : 1, gumbel_lut, flags, act_nodes, act_count, x));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -118,7 +140,7 @@ extern "C" int edgehip_active_select_train(const edgehip_layout* L, const int32_
     if (L->num_graphs == 0) return EDGEHIP_OK;
     hipLaunchKernelGGL(k_select<1>, dim3(L->num_graphs), dim3(256), 0, eh_stream(stream), *L, deg_tm1, deg_t,
                        (const int32_t*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, edgehip_rng{0}, 0,
-                       (const float*)nullptr, flags, act_nodes, act_count);
+                       (const float*)nullptr, flags, act_nodes, act_count, eh_select_extra{});
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
