@@ -1822,7 +1822,10 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_update_and_heavy_qt, dim3(nbu + gx * split), dim3(256), 0, s, *L, *P, ua,
                                nbu, d, gx, per));
         }
-        const int hb = Nn < 16384 ? Nn : 16384;          // single-wave blocks
+#ifndef EH_HEAVY_BLOCKS
+#define EH_HEAVY_BLOCKS 16384
+#endif
+        const int hb = Nn < EH_HEAVY_BLOCKS ? Nn : EH_HEAVY_BLOCKS;          // single-wave blocks
         switch (h) {
             case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
             case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;

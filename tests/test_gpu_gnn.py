@@ -102,6 +102,49 @@ def test_network_forward_vs_oracle_head_configs(heads):
     H.check_logits(logits, ref, TOL)
 
 
+@pytest.mark.parametrize('graph', ['ragged', 'polblogs'])
+def test_network_forward_with_sharp_attention_vs_oracle(graph):
+    """The attention walk keeps a softmax reference that moves only when a score leaves it 32 log2-units behind
+    (csrc/gnn.hip: eh_walk_step).  Random-init weights give scores within a few units of each other, so the move is
+    only taken at a row's first step; here query and key weights are scaled by 20 so that the scores of one row span
+    up to ~140 units and the reference has to move in mid-row: on the polblogs-shaped graph the CPU oracle counts
+    ~1 400 such moves in the 8-head layer (~260 of them on heavy rows, walked by k_attn_heavy) and ~400 in the
+    one-head layer.  The ragged graphs cover the short rows (spread up to ~90 units inside a row's first steps)."""
+    heads = (8, 1)
+    graphs = cases.ragged_graphs(5) if graph == 'ragged' else cases.polblogs_graph(0)
+    T = 48
+    dmax = cases.max_degree_of(graphs)
+    params = orc.random_tgnn_params(78, num_heads=heads)
+    for k in list(params):
+        if '.lin_query.' in k or '.lin_key.' in k:
+            params[k] = params[k] * 20.0
+    ob = orc.make_batch(graphs)
+    s = orc.make_schedule(T)
+    rng = np.random.default_rng(10)
+    ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+    ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+    Nn, P = ob.num_nodes, ob.full_edge_attr.shape[0]
+    t = 3
+    ob.log_node_attr_t, ob.log_full_edge_attr_t = orc.q_sample(
+        s, ob, torch.full((Nn,), t), torch.full((P,), t), orc.UniformTape([cases.uniforms(rng, Nn, 2), cases.uniforms(rng, P, 2)]))
+    u = cases.uniforms(rng, Nn, 2)
+    orc.p_sample_and_set_actives(s, ob, torch.full((Nn,), t), orc.UniformTape([u]))
+    assert len(ob.active_edge_indices) > 20
+    with torch.no_grad():
+        ref = orc.tgnn_forward(params, ob, torch.full((Nn,), t), dmax, T, heads)
+    import edgehip
+    a = H.make_args(T, dmax, heads=heads)
+    model = edgehip.get_model(a, None)
+    model._denoise_fn.load_state_dict(params)
+    model = model.cuda().eval()
+    b = H.graph_batch(graphs)
+    H.set_state_from_pair_indices(b, ob.log_full_edge_attr_t.argmax(1).nonzero(as_tuple=True)[0])
+    model._p_sample_and_set_actives(b, t, u.cuda())
+    _, logits = model._denoise_fn(b, torch.full((Nn,), t, device='cuda'), None)
+    assert logits.shape == ref.shape
+    H.check_logits(logits, ref, TOL)
+
+
 @pytest.mark.parametrize('differentiable', [False, True], ids=['fused', 'train_ops'])
 @pytest.mark.parametrize('name,case', [('loss_toy', 'toy'), ('loss_toy_mid', 'toy'), ('loss_ragged', 'ragged'),
                                        ('loss_polblogs1', 'polblogs1')])
