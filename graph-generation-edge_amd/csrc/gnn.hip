@@ -1887,21 +1887,28 @@ struct eh_pair_args {
     float* tile_partial; int64_t tile_cap;
 };
 
+#ifndef EH_PAIR_BLOCKS
+#define EH_PAIR_BLOCKS 512                 // two resident blocks per CU: the 48 KB of weights are staged once per block
+#endif
+#define EH_PAIR_SP 36                      // row pitch (floats) of the staging tile: 16-byte aligned rows
+#define EH_PAIR_WBUF (32 * EH_PAIR_SP)     // floats per wave
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) {
     // The address unit bounds this kernel when the active sets are large (68 % TA busy at 684 k pairs per step): per
     // 32-pair tile a wave issued 32 loads for its two node rows, 16 for the bias and 48 for the four weight fragments,
     // the same 48 KB of weights for every tile.  The block now holds the fragments and the bias in LDS (one copy per
     // block and launch), and the hidden tile passes through LDS in two halves of 32 columns, which keeps two blocks per CU.
-    __shared__ float hid[4][32][33];
+    // per wave: one [32][36] tile, first the staging tile of operand b, then the hidden tile for the final dot
+    __shared__ __attribute__((aligned(16))) float hbuf[4 * EH_PAIR_WBUF];
     __shared__ __attribute__((aligned(16))) float b0s[128];       // final_out.0 bias
+    __shared__ __attribute__((aligned(16))) float w4s[128];       // final_out.4 weight [2][64]
     __shared__ __attribute__((aligned(16))) float wlds[4 * EH_PK_TILE];   // final_out.2 fragments (nt, ch) = tile nt * 2 + ch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int total = a.counts->pair_tiles;
     const int B = L.num_graphs;
     if ((int)blockIdx.x * 4 >= total) return;
     if (!a.logits_in) {
-        if (threadIdx.x < 128) b0s[threadIdx.x] = a.fb0[threadIdx.x];
+        if (threadIdx.x < 128) { b0s[threadIdx.x] = a.fb0[threadIdx.x]; w4s[threadIdx.x] = a.fw4[threadIdx.x]; }
         for (int i = threadIdx.x; i < EH_PK_TILE; i += 256)
             reinterpret_cast<f32x4*>(wlds)[i] = reinterpret_cast<const f32x4*>(a.pfw2)[i];
     }
@@ -1932,13 +1939,38 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
         f32x16 hacc0 = eh_zero16(), hacc1 = eh_zero16();      // hidden tile of this wave (columns r and 32 + r)
         if (valid && !a.logits_in) {
             const float* va = a.node_repr + (size_t)(kbase + p) * 128;
-            const float* vb = a.node_repr + (size_t)(kbase + q) * 128;
             f32x16 acc0 = eh_zero16(), acc1 = eh_zero16();
+            // Operand a: the pairs of a tile run along a row of the triangle, so its lanes share one or two rows of
+            // node_repr and a fragment load touches a line or two.  Operand b is a different row in every lane: read
+            // as fragments, each of the 8 loads touches 64 lines (the address unit was 68 % busy at 684 k pairs per
+            // step).  Its rows come in whole 128-byte pieces instead (lane = row 8i + lane/8, 16-byte piece lane%8:
+            // 8 lines per load) and pass through a wave-private LDS tile in two 32-column halves; LDS operations of a
+            // wave execute in order, so the tile needs no second buffer.
+            float* stg = hbuf + wave * EH_PAIR_WBUF;
+            const int srow = lane >> 3, spc = lane & 7;
+            int qrow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qrow[i] = __shfl(q, 8 * i + srow);
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int ko = ch * 64 + hh * 32;
                 eh_frag fa, fb, fc, e;
-                eh_load_frag(fa, va + ko); eh_load_frag(fb, vb + ko); eh_load_frag(fc, b0s + ko);
+                eh_load_frag(fa, va + ko); eh_load_frag(fc, b0s + ko);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 tv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        tv[i] = *reinterpret_cast<const f32x4*>(a.node_repr + (size_t)(kbase + qrow[i]) * 128 + ch * 64 + half * 32 + spc * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(stg + (8 * i + srow) * EH_PAIR_SP + spc * 4) = tv[i];
+                    __builtin_amdgcn_wave_barrier();
+                    if (hh == half) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) fb.v[i] = *reinterpret_cast<const f32x4*>(stg + r * EH_PAIR_SP + 4 * i);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1965,20 +1997,28 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
         if (a.logits_in) {
             if (live) logit = a.logits_in[(abase + k) * 2 + c];
         } else {
-            const float* w4 = a.fw4 + c * 64;
+            // weights from LDS (as 64 per-lane global loads per tile they were most of the kernel's address-unit time);
+            // hidden row and weights come four at a time, the sum keeps its order
+            const float* w4 = w4s + c * 64;
             float s = a.fb4[c];
 #pragma unroll
             for (int half2 = 0; half2 < 2; ++half2) {
                 if (valid) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) hid[wave][eh_crow(i, lane)][r] = half2 ? hacc1[i] : hacc0[i];
+                    for (int i = 0; i < 16; ++i) hbuf[wave * EH_PAIR_WBUF + eh_crow(i, lane) * EH_PAIR_SP + r] = half2 ? hacc1[i] : hacc0[i];
                 }
-                __syncthreads();
+                // the tile is private to the wave and a wave's LDS operations execute in order: no block barrier
+                // (four of them per tile kept the block's waves in lockstep)
+                __builtin_amdgcn_wave_barrier();
                 if (live) {
-#pragma unroll 8
-                    for (int d = 0; d < 32; ++d) s += hid[wave][pr][d] * w4[32 * half2 + d];
+#pragma unroll
+                    for (int d = 0; d < 32; d += 4) {
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + wave * EH_PAIR_WBUF + pr * EH_PAIR_SP + d);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(w4 + 32 * half2 + d);
+                        s += hv[0] * wv[0]; s += hv[1] * wv[1]; s += hv[2] * wv[2]; s += hv[3] * wv[3];
+                    }
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
             logit = s;
         }
@@ -2069,7 +2109,7 @@ extern "C" int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_
     a.logits_in = logits_in; a.logits_are_logprobs = logits_are_logprobs;
     a.uniforms = uniforms; a.rng = rng ? *rng : edgehip_rng{0}; a.use_rng = uniforms ? 0 : 1; a.step = step;
     a.lut = gumbel_lut; a.adj = adj; a.logits_out = logits_out; a.bits_out = bits_out; a.pair_cap = pair_cap;
-    EH_PROF(EH_K_PAIR, eh_stream(stream), hipLaunchKernelGGL(k_pair<0>, dim3(2048), dim3(256), 0, eh_stream(stream), *L, a));
+    EH_PROF(EH_K_PAIR, eh_stream(stream), hipLaunchKernelGGL(k_pair<0>, dim3(EH_PAIR_BLOCKS), dim3(256), 0, eh_stream(stream), *L, a));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
 }
@@ -2105,7 +2145,7 @@ extern "C" int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_p
     eh_fill_pair_weights(a, P, folded);
     a.adj = const_cast<uint32_t*>(adj_tm1); a.logits_out = logits_out; a.pair_cap = pair_cap;
     a.tile_partial = tile_partial; a.tile_cap = tile_cap;
-    EH_PROF(EH_K_PAIR, eh_stream(stream), hipLaunchKernelGGL(k_pair<1>, dim3(2048), dim3(256), 0, eh_stream(stream), *L, a));
+    EH_PROF(EH_K_PAIR, eh_stream(stream), hipLaunchKernelGGL(k_pair<1>, dim3(EH_PAIR_BLOCKS), dim3(256), 0, eh_stream(stream), *L, a));
     hipLaunchKernelGGL(k_kl_reduce, dim3((L->num_graphs + 63) / 64), dim3(64), 0, eh_stream(stream), *L, tptr, aptr,
                        tile_partial, kl);
     EH_LAUNCH_CHECK();
