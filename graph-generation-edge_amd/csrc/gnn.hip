@@ -539,23 +539,19 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
     if (tid < width) {
         // eight independent partial sums: the tile loads of a trip are all in flight together (a plain
         // `s += part[..]` loop waits for every load in turn: ~40 L2 round trips per launch)
+        // 24 tiles per trip (a trip costs one L2 round trip; 39 tiles of a polblogs graph: two trips); the sums keep
+        // the order of 8-tile trips: tile t0 + 8k + j goes to ps[j], k ascending (masked tiles add 0)
         float ps[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) ps[j] = 0.f;
-        int t = t0;
-        for (; t + 8 <= t1; t += 8) {
-            float x[8];
+        for (int t = t0; t < t1; t += 24) {
+            float x[24];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = part[(size_t)(t + j) * 256 + tid];
+            for (int j = 0; j < 24; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ps[j] += x[j];
-        }
-        {
-            float x[8];
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ps[j] += x[j];
+                for (int j = 0; j < 8; ++j) ps[j] += x[8 * k + j];
         }
         const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
         mean[tid] = s / (float)(n > 0 ? n : 1);
@@ -591,14 +587,47 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
         const int count = first + per <= lp.H ? per : (lp.H > first ? lp.H - first : 0);
         eh_block_gemv<64, true>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
     }
-    {   // cbias = context_b0 + context_w0[:, 64:128] . ctx             64 rows per part
-        eh_block_gemv<64, false>(P.context_w0 + 64, 128, cn, nullptr, 0, nullptr, P.context_b0, prt * (256 / EH_GU_PARTS),
-                                 256 / EH_GU_PARTS, cbias + (size_t)g * 256, 0);
+    // cbias = context_b0 + context_w0[:, 64:128] . ctx (64 rows per part) and, on parts 1 and 2,
+    // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx  /  obias1 = bvbar + Vbbar . te + Vsum . ctx:
+    // 64 outputs each, their weight rows requested together (one L2 round trip instead of two; same arithmetic)
+    {
+        static_assert(256 / EH_GU_PARTS == 64, "four passes of 16 outputs per job");
+        const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, kq = lane & 15;
+        const bool two = prt == 1 || prt == 2;                         // block-uniform
+        const float* Wt = prt == 1 ? lp.skip_w + 64 : lp.Vbbar;        // . te
+        const float* Wx = prt == 1 ? lp.skip_w : lp.Vsum;              // . ctx (layer 0: zeros)
+        const int ldo = prt == 1 ? 128 : 64;
+        const float* ob = prt == 1 ? lp.skip_b : lp.bvbar;
+        float* oy = (prt == 1 ? obias0 : obias1) + (size_t)g * 64;
+        const f32x4 xcn = *reinterpret_cast<const f32x4*>(cn + 4 * kq);
+        const f32x4 xte = *reinterpret_cast<const f32x4*>(tev + 4 * kq);
+        const f32x4 xx = *reinterpret_cast<const f32x4*>(xc + 4 * kq);
+        f32x4 wc[4], wt[4], wx[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int o = 16 * p + 4 * wave + sub;
+            wc[p] = *reinterpret_cast<const f32x4*>(P.context_w0 + 64 + (size_t)(prt * 64 + o) * 128 + 4 * kq);
+            if (two) {
+                wt[p] = *reinterpret_cast<const f32x4*>(Wt + (size_t)o * ldo + 4 * kq);
+                wx[p] = *reinterpret_cast<const f32x4*>(Wx + (size_t)o * ldo + 4 * kq);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int o = 16 * p + 4 * wave + sub;
+            float sc = 0.f;
+            sc += wc[p][0] * xcn[0] + wc[p][1] * xcn[1] + wc[p][2] * xcn[2] + wc[p][3] * xcn[3];
+            sc = eh_row16_sum(sc);
+            if (kq == 0) cbias[(size_t)g * 256 + prt * 64 + o] = sc + P.context_b0[prt * 64 + o];
+            if (two) {
+                float so = 0.f;
+                so += wt[p][0] * xte[0] + wt[p][1] * xte[1] + wt[p][2] * xte[2] + wt[p][3] * xte[3];
+                so += wx[p][0] * xx[0] + wx[p][1] * xx[1] + wx[p][2] * xx[2] + wx[p][3] * xx[3];
+                so = eh_row16_sum(so);
+                if (kq == 0) oy[o] = so + ob[o];
+            }
+        }
     }
-    if (prt == 1)       // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx
-        eh_block_gemv<64, true>(lp.skip_w + 64, 128, tev, lp.skip_w, 128, xc, lp.skip_b, 0, 64, obias0 + (size_t)g * 64, 0);
-    if (prt == 2)       // obias1 = bvbar + Vbbar . te + Vsum . ctx
-        eh_block_gemv<64, true>(lp.Vbbar, 64, tev, lp.Vsum, 64, xc, lp.bvbar, 0, 64, obias1 + (size_t)g * 64, 0);
     if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
 }
 
