@@ -898,7 +898,8 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
 // load instruction brings four whole rows (lane = 16-byte piece), the rows go to a wave-private LDS tile and the
 // lanes read their channels from there (identical addresses broadcast): 4 TA cycles per visit.  LDS operations of a
 // wave execute in order, so the tile needs no second buffer: the reads of step s are issued before the write of
-// step s + 1.  Pipeline: offsets three steps ahead, global loads two steps ahead, LDS reads one step ahead.
+// step s + 1.  Pipeline: global loads EH_WALK_DEPTH steps ahead (a ring of 4-register loads), their offsets one step
+// earlier still, LDS reads one step ahead.
 #define EH_SGP 68                                  // row pitch of the staging tile (floats)
 #ifndef EH_WALK_DEPTH
 #define EH_WALK_DEPTH 2                            // even (the two register sets of the visits alternate); 4, 6, 8 measured: no change
@@ -1392,9 +1393,9 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
                 // load instruction per four rows instead of eight per-lane gathers of the same bytes; the address
                 // unit was busy 59 % of this kernel).  The tile lives in the h tile's LDS (hp), which phase A has
-                // finished with and which is loaded again before phase C.  Offsets run three steps ahead, global
-                // loads two, LDS reads one; steps past the end are skipped by predication (their clamped fetches
-                // are hits) so that the loop has ONE exit.
+                // finished with and which is loaded again before phase C.  Global loads run EH_WALK_DEPTH steps
+                // ahead, their offsets one more, LDS reads one; steps past the end are skipped by predication (their
+                // clamped fetches are hits) so that the loop has ONE exit.
                 constexpr int NLD = UN / 4;
                 float* stage = hp + wave * (UN * EH_SGP);
                 const int lrow = lane >> 4, lpart = lane & 15;
