@@ -1,4 +1,9 @@
-# experiment builds (exp_libs/libedgehip_<V>.so) against the default library on fixed states
+#!/bin/bash
+# Times experiment builds of the library against the default one on fixed states (tools/kbench.py: one reverse step at
+# a given t, repeated).  An experiment build is gnn.hip compiled with extra -D switches (EH_EXP_*: timing only, wrong
+# results by construction; EH_WALK_DEPTH, EH_HEAVY_DEG, EH_HEAVY_BLOCKS, EH_PAIR_BLOCKS, EH_CPL: tunables) and linked
+# with the other objects into exp_libs/libedgehip_<NAME>.so (git-ignored); kbench picks it up through EDGEHIP_LIB.
+#   bash tools/exp_sweep.sh NAME [NAME ...]      (through gpurun, from the repo root)
 set -e
 for V in base "$@"; do
   if [ $V = base ]; then unset EDGEHIP_LIB; else export EDGEHIP_LIB=$PWD/exp_libs/libedgehip_$V.so; fi
