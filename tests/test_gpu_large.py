@@ -20,8 +20,67 @@ def test_reverse_step_vs_oracle_other_shapes(shape, t_step):
     edges bit-exact, logits within 1e-4 of the oracle on the same uniforms."""
     from edgehip import synth
     n, edges = getattr(synth, shape)(0)
-    graphs = [dict(n=n, edges=edges)]
-    T = 512
+    _reverse_step_vs_oracle([dict(n=n, edges=edges)], t_step, 512)
+
+
+def _many_small_graphs(count, seed=5):
+    """`count` graphs of 6..70 nodes; every 7th is a star of 60 leaves with a few extra edges (a heavy row: more than
+    48 neighbours), every 50th a star of 170 leaves (a long row: more than 128 neighbours still at x_t), every 11th has no edge at all."""
+    rng = np.random.default_rng(seed)
+    gs = []
+    for k in range(count):
+        if k % 50 == 49:
+            n = 171
+            e = [(0, j) for j in range(1, n)]
+        elif k % 7 == 6:
+            n = 61 + int(rng.integers(0, 9))
+            e = [(0, j) for j in range(1, 61)] + [(int(a), int(a) + 1) for a in rng.integers(1, n - 1, 12)]
+        elif k % 11 == 10:
+            n = 6 + int(rng.integers(0, 30))
+            e = []
+        else:
+            n = 6 + int(rng.integers(0, 65))
+            gs.append(dict(n=n, edges=cases.random_graph(rng, n, min(1.0, 3.0 / n))))
+            continue
+        ed = np.unique(np.array([(min(a, b), max(a, b)) for a, b in e if a != b], dtype=np.int64).reshape(-1, 2), axis=0)
+        gs.append(dict(n=n, edges=ed))
+    return gs
+
+
+def test_reverse_step_vs_oracle_many_graphs():
+    """600 graphs in one batch (the reference trains Ego / Community with batches of up to 512 graphs): more graphs
+    than an XCD's share of 8, per-graph heavy and long lists that are mostly empty, graphs without any edge, more
+    graphs than the 256 threads of the offsets scan.  Same bar as the single-graph shapes."""
+    gs = _many_small_graphs(600)
+    assert sum(1 for g in gs if len(g['edges']) == 0) > 20
+    _reverse_step_vs_oracle(gs, 6, 64, min_pairs=2000, min_nodes=500, min_max_degree=129)
+
+
+def test_many_graphs_fused_trajectory_equals_stepwise_and_split_runs():
+    """The same 600 graphs through the fused sampler (one launch chain per reverse step; its selection launch also
+    writes t and clears the heavy-row counters) against the op-by-op path, on one stream and cut into three blocks of
+    graphs: edge lists bit-identical."""
+    from edgehip import capi
+    gs = _many_small_graphs(600)
+    T, seed = 24, 4242
+    dmax = cases.max_degree_of(gs)
+    model = H.build_model(orc.random_tgnn_params(6), T, dmax)
+    b1 = H.graph_batch(gs, with_edges=False)
+    model.sample_batch(b1, seed, parts=1)
+    b2 = H.graph_batch(gs, with_edges=False)
+    b2.adj.zero_()
+    for t in reversed(range(T)):
+        model.p_sample(b2, t, None, None, capi.Rng(seed))
+    model._finish_sample(b2)
+    assert b1.edge_index.shape[1] > 5000
+    assert torch.equal(b1.edge_index, b2.edge_index)
+    b3 = H.graph_batch(gs, with_edges=False)
+    model.sample_batch(b3, seed, parts=3)
+    assert torch.equal(b1.edge_index, b3.edge_index)
+    assert torch.equal(b1._slice_dict['edge_index'], b3._slice_dict['edge_index'])
+
+
+def _reverse_step_vs_oracle(graphs, t_step, T, min_pairs=300, min_nodes=20, min_max_degree=0):
     dmax = cases.max_degree_of(graphs)
     params = orc.random_tgnn_params(31)
     rng = np.random.default_rng(77)
@@ -46,7 +105,8 @@ def test_reverse_step_vs_oracle_other_shapes(shape, t_step):
     with torch.no_grad():
         _, out_edge = o.p_sample(ob, tn, orc.CallbackTape(tape_fn), rec)
     A = len(rec['active_edge_indices'])
-    assert A > 300 and len(rec['active_node_indices']) > 20
+    assert A > min_pairs and len(rec['active_node_indices']) > min_nodes
+    assert int(rec['degree_t'].max()) >= min_max_degree
 
     model = H.build_model(params, T, dmax)
     b = H.graph_batch(graphs)
