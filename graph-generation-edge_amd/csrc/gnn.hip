@@ -789,11 +789,25 @@ __device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc
 // The walk keeps its scores in the log2 domain: qt rows are multiplied by log2(e) once per target, so every
 // softmax weight is one v_exp_f32 (2^x) without the per-visit multiply of exp(x) = 2^(x log2 e).
 __device__ static inline float eh_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifndef EH_REF_SLACK
 #define EH_REF_SLACK 32.f       // log2 units a score may exceed the softmax reference before the reference moves
+#endif
 __device__ static inline void eh_scale_q_log2e(f32x2 (&q)[EH_CPL / 2]) {
     const f32x2 k = f32x2{1.4426950408889634f, 1.4426950408889634f};
 #pragma unroll
     for (int d = 0; d < EH_CPL / 2; ++d) q[d] *= k;
+}
+
+// lane ^ 4 inside a row of 16: the lanes of banks 0 and 2 read four lanes up, those of banks 1 and 3 four lanes down
+__device__ static inline float eh_dpp_xor4(float v) {
+    const int a = __builtin_bit_cast(int, v);
+    int r = __builtin_amdgcn_update_dpp(0, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, a, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+    return __builtin_bit_cast(float, r);
+}
+template <int K>
+__device__ static inline float eh_quad_bcast(float v) {         // lane K of every quad to the quad's four lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xF, 0xF, true));
 }
 
 __device__ static inline float eh_group_sum(float v) {          // over the EH_LG lanes of a group
@@ -820,6 +834,60 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
 #endif
     float sc[U];
     float mn = m;
+    if constexpr (U == 4 && NSLOT == 1 && EH_LG == 8) {
+        // Eight heads: the 8 lanes of a head hold partial scores of the step's 4 visits.  Summed as an all-reduce (3 DPP
+        // adds per visit) every lane ends with all four scores and then computes the same four weights - eight times
+        // over, and v_exp_f32 runs at a quarter of the rate.  Here the sums are a reduce-scatter over the same tree
+        // (lane c keeps visit c & 3: selects + 4 DPP adds, the operands of every add unchanged, so the sums are
+        // bit-identical), ONE exp per lane gives the weight of the lane's visit and quad broadcasts hand the four
+        // weights round: ~20 issue slots instead of ~32 for scores-to-weights of a step.
+        const int ln = (int)(threadIdx.x & 63);
+        const bool b0 = (ln & 1) != 0, b1 = (ln & 2) != 0;
+        float t[4];
+        f32x2 t2[4];                              // the four chains side by side: a dependent packed FMA needs a wait state
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t2[u] = q[0] * x[u].p[0];
+#pragma unroll
+        for (int d = 1; d < EH_CPL / 2; ++d)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t2[u] = __builtin_elementwise_fma(q[d], x[u].p[d], t2[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = t2[u][0] + t2[u][1];
+        const float k0 = b0 ? t[1] : t[0], s0 = b0 ? t[0] : t[1];
+        const float k1 = b0 ? t[3] : t[2], s1 = b0 ? t[2] : t[3];
+        const float r0 = k0 + eh_dpp_f(s0, 0), r1 = k1 + eh_dpp_f(s1, 0);          // visits b0 and 2 + b0 over lane pairs
+        const float kk = b1 ? r1 : r0, ss = b1 ? r0 : r1;
+        const float qv = kk + eh_dpp_f(ss, 1);                                      // visit ln & 3 over the quad
+        float sv = qv + eh_dpp_xor4(qv);                                            // .. over the head's 8 lanes
+        if (nvalid < UN) {                       // wave-uniform: only the last step of a list has filler visits
+            asm volatile("" ::: "memory");
+            sv = ((ln & 3) < nvalid) ? sv : -INFINITY;
+        }
+        if (__any(sv > m + EH_REF_SLACK)) {      // the reference moves to the maximum of the step (see below)
+            float g = fmaxf(sv, eh_dpp_f(sv, 0));
+            g = fmaxf(g, eh_dpp_f(g, 1));                                           // the quad holds all four visits
+            mn = fmaxf(m, g);
+            const float resc = eh_exp2(m - mn);
+            lsum *= resc;
+            const f32x2 r2 = f32x2{resc, resc};
+#pragma unroll
+            for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
+            m = mn;
+        }
+        const float pw = eh_exp2(sv - m);
+        sc[0] = eh_quad_bcast<0>(pw); sc[1] = eh_quad_bcast<1>(pw); sc[2] = eh_quad_bcast<2>(pw); sc[3] = eh_quad_bcast<3>(pw);
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ps += sc[u];
+        lsum += ps;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x2 p2 = f32x2{sc[u], sc[u]};
+#pragma unroll
+            for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = __builtin_elementwise_fma(p2, x[u].p[d], acc[d]);
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         f32x2 t2 = q[0] * x[u].p[0];
