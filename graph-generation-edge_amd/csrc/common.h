@@ -19,6 +19,18 @@ int eh_active_select_step(const edgehip_layout* L, const int32_t* d0, const int3
                           const float* gumbel_lut, uint8_t* flags, int32_t* act_nodes, int32_t* act_count,
                           int32_t* clear, int clear_n, hipStream_t s);
 
+// inclusive prefix sum over the 64 lanes on the DPP path (row shifts 1, 2, 4, 8 with zero fill, then the row totals
+// handed to the next rows): six vector instructions instead of six LDS-crossbar shuffles with their index arithmetic
+__device__ static inline int eh_wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xA, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xC, 0xF, true);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based.  One call gives 4 x 32 random bits.
 // ---------------------------------------------------------------------------------------------

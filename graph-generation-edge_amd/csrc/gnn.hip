@@ -651,11 +651,7 @@ __device__ static inline void eh_heavy_qt_body(const eh_hq_args& d, int ng_per_b
     for (int base = 0; base < d.nseg; base += 64) {
         const int gi = base + lane;
         int incl = gi < d.nseg ? d.seg_lo[gi] + d.seg_hi[gi] : 0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
+        incl = eh_wave_scan_incl(incl);
         const int tot = __builtin_amdgcn_readlane(incl, 63);
         if (run + tot > m0 && run < m0 + 32) {
             for (int rr = 0; rr < 32; ++rr) {
@@ -1120,11 +1116,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             uint32_t w = (lane < EH_HCHUNK && w0 + lane < stride) ? rowp[w0 + lane] : 0u;
             const int cnt = __popc(w);
             int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
-            }
+            incl = eh_wave_scan_incl(incl);
             const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0) continue;
             int pos = incl - cnt;
@@ -1358,13 +1350,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 #pragma unroll
             for (int k = 0; k < 8; ++k) { cnt[k] = __popc(fw[k]); incl[k] = cnt[k]; }
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    int t = __shfl_up(incl[k], d);
-                    if (lane >= d) incl[k] += t;
-                }
-            }
+            for (int k = 0; k < 8; ++k) incl[k] = eh_wave_scan_incl(incl[k]);
             int off = 0;          // wave-uniform: start of target k's (padded) list
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1385,11 +1371,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                             uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
                             const int c2 = __popc(w2);
                             int in2 = c2;
-#pragma unroll
-                            for (int d = 1; d < 64; d <<= 1) {
-                                int t = __shfl_up(in2, d);
-                                if (lane >= d) in2 += t;
-                            }
+                            in2 = eh_wave_scan_incl(in2);
                             int p2 = base + in2 - c2;
                             const int jb2 = node0 + (w0 + lane) * 32;
                             while (w2) {
