@@ -75,13 +75,15 @@ typedef unsigned int eh_u32x4 __attribute__((ext_vector_type(4)));
 struct eh_frag3 { eh_u32x4 h[4], m[4], l[4]; };      // [i]: k-group 8i..8i+7 of the lane's 32 k, bf16 pairs in dwords
 
 __device__ static inline void eh_split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+    typedef float eh_f2 __attribute__((ext_vector_type(2)));
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    // the two remainders of a pair as ONE packed subtraction each (exact either way)
+    const eh_f2 r = eh_f2{x0, x1} - eh_f2{__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
+    const unsigned v0 = __float_as_uint(r[0]), v1 = __float_as_uint(r[1]);
+    const eh_f2 t = r - eh_f2{__uint_as_float(v0 & 0xffff0000u), __uint_as_float(v1 & 0xffff0000u)};
     ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);          // upper halves: element 0 in the low 16 bits
     pm = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
 }
 __device__ static inline void eh_split3(eh_frag3& o, const eh_frag& f) {
 #pragma unroll
