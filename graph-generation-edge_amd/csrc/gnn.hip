@@ -817,7 +817,7 @@ __device__ static inline float eh_group_sum(float v) {          // over the EH_L
 // nvalid: real visits left in the list at this step (>= UN: no masking needed).
 template <int HEADS>
 __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const eh_xr (&x)[eh_walk_cfg<HEADS>::U], int nvalid,
-                                           int slot, f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
+                                           int slot, f32x2 (&acc)[EH_CPL / 2], float& m, float& mthr, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
 #ifdef EH_EXP_NOCOMPUTE         // timing experiment only: consume the loads, skip the softmax arithmetic
 #pragma unroll
@@ -859,7 +859,7 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
             asm volatile("" ::: "memory");
             sv = ((ln & 3) < nvalid) ? sv : -INFINITY;
         }
-        if (__any(sv > m + EH_REF_SLACK)) {      // the reference moves to the maximum of the step (see below)
+        if (__any(sv > mthr)) {                  // mthr = m + EH_REF_SLACK: the reference moves to the maximum of the step (see below)
             float g = fmaxf(sv, eh_dpp_f(sv, 0));
             g = fmaxf(g, eh_dpp_f(g, 1));                                           // the quad holds all four visits
             mn = fmaxf(m, g);
@@ -869,12 +869,13 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
             m = mn;
+            mthr = mn + EH_REF_SLACK;
         }
         const float pw = eh_exp2(sv - m);
         sc[0] = eh_quad_bcast<0>(pw); sc[1] = eh_quad_bcast<1>(pw); sc[2] = eh_quad_bcast<2>(pw); sc[3] = eh_quad_bcast<3>(pw);
-        float ps = 0.f;
+        float ps = sc[0];                         // (0 + p0 = p0: the weights are >= +0)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ps += sc[u];
+        for (int u = 1; u < 4; ++u) ps += sc[u];
         lsum += ps;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -903,13 +904,14 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
     // step of a row, then rarely).  Weights stay below 2^EH_REF_SLACK, relative precision is that of fp32 either
     // way, and a step that keeps its reference costs neither the rescale factor (a quarter-rate exp) nor the
     // multiplies of acc and lsum.
-    if (__any(mn > m + EH_REF_SLACK)) {
+    if (__any(mn > mthr)) {                      // mthr = m + EH_REF_SLACK, kept beside m
         const float resc = eh_exp2(m - mn);
         lsum *= resc;
         const f32x2 r2 = f32x2{resc, resc};
 #pragma unroll
         for (int d = 0; d < EH_CPL / 2; ++d) acc[d] *= r2;
         m = mn;
+        mthr = mn + EH_REF_SLACK;
     }
     float ps = 0.f;
 #pragma unroll
@@ -926,7 +928,7 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
 template <int HEADS>
 __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
                                            const f32x2 (&q)[EH_CPL / 2], int lane, f32x2 (&acc)[EH_CPL / 2], float& m,
-                                           float& lsum) {
+                                           float& mthr, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
     const int grp = lane / EH_LG, c = lane % EH_LG;
     const int slot = grp / HEADS;
@@ -945,12 +947,12 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
     for (int gs = 0; gs < nsteps; gs += 2) {
         fetch(gs + 1 < lastg ? gs + 1 : lastg, xb);
         __builtin_amdgcn_sched_barrier(0);
-        eh_walk_step<HEADS>(q, xa, nvis - gs * UN, slot, acc, m, lsum);
+        eh_walk_step<HEADS>(q, xa, nvis - gs * UN, slot, acc, m, mthr, lsum);
         __builtin_amdgcn_sched_barrier(0);
         if (gs + 1 >= nsteps) break;
         fetch(gs + 2 < lastg ? gs + 2 : lastg, xa);
         __builtin_amdgcn_sched_barrier(0);
-        eh_walk_step<HEADS>(q, xb, nvis - (gs + 1) * UN, slot, acc, m, lsum);
+        eh_walk_step<HEADS>(q, xb, nvis - (gs + 1) * UN, slot, acc, m, mthr, lsum);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -972,7 +974,7 @@ template <int HEADS>
 __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ list, int nvis, const float* __restrict__ hsrc,
                                                   float* __restrict__ stage /* [UN][EH_SGP] of this wave */,
                                                   const f32x2 (&q)[EH_CPL / 2], int lane, f32x2 (&acc)[EH_CPL / 2],
-                                                  float& m, float& lsum) {
+                                                  float& m, float& mthr, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
     constexpr int NLD = UN / 4;                    // load instructions per step: four 256-byte rows each
     static_assert(UN % 4 == 0, "four rows per load instruction");
@@ -1023,7 +1025,7 @@ __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ l
             // steps past the end are skipped by predication (their clamped fetches are hits): ONE loop exit
             advance(g[(j + 1) % D], gs + j + 2 + D, x[(j + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (gs + j < nsteps) eh_walk_step<HEADS>(q, x[j & 1], nvis - (gs + j) * UN, slot, acc, m, lsum);
+            if (gs + j < nsteps) eh_walk_step<HEADS>(q, x[j & 1], nvis - (gs + j) * UN, slot, acc, m, mthr, lsum);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
         const int stride = L.adj_stride[g];
         const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
         f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
-        float m = -1e30f, lsum = 0.f;
+        float m = -1e30f, lsum = 0.f, mthr = -1e30f + EH_REF_SLACK;
         {
             // qt row of the gathered GEMM + the per-graph bias (time embedding / context terms)
             f32x2 qb[EH_CPL / 2];
@@ -1125,8 +1127,8 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
             if (lane < UN) list[total + lane] = (uint32_t)node * 256u;   // filler visits of the last step (masked)
             EH_LDS_SYNC();
             // HEADS >= 4: the head groups of a slot would gather the same bytes 4-8 times - go through LDS
-            if constexpr (HEADS >= 4) eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, lsum);
-            else eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, lsum);
+            if constexpr (HEADS >= 4) eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, mthr, lsum);
+            else eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, mthr, lsum);
             EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
         }
         eh_merge_slots<HEADS>(acc, m, lsum);
@@ -1396,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         // (c) the flat walk
         {
             f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
-            float mrun = -1e30f, lrun = 0.f;
+            float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
             int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
@@ -1424,9 +1426,9 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                     eh_scale_q_log2e(q);
 #pragma unroll
                     for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
-                    mrun = -1e30f; lrun = 0.f;            // finite floor: exp(-1e30 - x) = 0 and never inf - inf
+                    mrun = -1e30f; lrun = 0.f; mthr = -1e30f + EH_REF_SLACK;   // finite floor: exp(-1e30 - x) = 0 and never inf - inf
                 }
-                eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, lrun);
+                eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, mthr, lrun);
                 ++st;
                 if (st == nst) {                         // target finished: merge the slots, write z over its qt row
                     eh_merge_slots<HEADS>(acc, mrun, lrun);
