@@ -794,12 +794,17 @@ __device__ static inline void eh_scale_q_log2e(f32x2 (&q)[EH_CPL / 2]) {
     for (int d = 0; d < EH_CPL / 2; ++d) q[d] *= k;
 }
 
-// lane ^ 4 inside a row of 16: the lanes of banks 0 and 2 read four lanes up, those of banks 1 and 3 four lanes down
-__device__ static inline float eh_dpp_xor4(float v) {
-    const int a = __builtin_bit_cast(int, v);
-    int r = __builtin_amdgcn_update_dpp(0, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
-    r = __builtin_amdgcn_update_dpp(r, a, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
-    return __builtin_bit_cast(float, r);
+// v + v[lane ^ 4] inside a row of 16: two bank-masked DPP adds into one register - the lanes of banks 0 and 2 add the
+// value four lanes up, those of banks 1 and 3 the value four lanes down.  Written as instructions because the DPP
+// combiner does not fuse bank-masked moves (it left mov 0, mov_dpp, mov_dpp, add); the s_nop covers the two wait
+// states a DPP read needs after the vector write of its source.
+__device__ static inline float eh_dpp_xor4_add(float v) {
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(v));
+    return r;
 }
 template <int K>
 __device__ static inline float eh_quad_bcast(float v) {         // lane K of every quad to the quad's four lanes
@@ -854,7 +859,7 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
         const float r0 = k0 + eh_dpp_f(s0, 0), r1 = k1 + eh_dpp_f(s1, 0);          // visits b0 and 2 + b0 over lane pairs
         const float kk = b1 ? r1 : r0, ss = b1 ? r0 : r1;
         const float qv = kk + eh_dpp_f(ss, 1);                                      // visit ln & 3 over the quad
-        float sv = qv + eh_dpp_xor4(qv);                                            // .. over the head's 8 lanes
+        float sv = eh_dpp_xor4_add(qv);                                             // .. over the head's 8 lanes
         if (nvalid < UN) {                       // wave-uniform: only the last step of a list has filler visits
             asm volatile("" ::: "memory");
             sv = ((ln & 3) < nvalid) ? sv : -INFINITY;
