@@ -802,7 +802,8 @@ __device__ static inline float eh_dpp_xor4_add(float v) {
     float r;
     asm volatile("s_nop 1\n\t"
                  "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "s_nop 1"                     // the hazard recognizer does not see these writes: a DPP read of r may follow
                  : "=&v"(r) : "v"(v));
     return r;
 }
