@@ -911,6 +911,9 @@ __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const e
     // way, and a step that keeps its reference costs neither the rescale factor (a quarter-rate exp) nor the
     // multiplies of acc and lsum.
     if (__any(mn > mthr)) {                      // mthr = m + EH_REF_SLACK, kept beside m
+        // the slots of a head keep ONE reference (the maximum over all of them): their states then merge by plain sums
+#pragma unroll
+        for (int o = EH_LG * HEADS; o < 64; o <<= 1) mn = fmaxf(mn, __shfl_xor(mn, o));
         const float resc = eh_exp2(m - mn);
         lsum *= resc;
         const f32x2 r2 = f32x2{resc, resc};
@@ -1037,23 +1040,41 @@ __device__ static inline void eh_walk_list_staged(const uint32_t* __restrict__ l
     }
 }
 
-// merge the online-softmax states of the slots (all lanes end with the merged state)
+// v + v[lane ^ O] for O = 8, 16, 32 without the LDS crossbar: a row rotation, and the two lane-swap instructions of
+// gfx950 (each returns both halves of the exchange, own + partner in one order or the other)
+template <int O>
+__device__ static inline float eh_xor_sum(float v) {
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    if constexpr (O == 8) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, (int)a, 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+    } else {
+        // the swap instructions exchange halves of TWO registers in place (rows 1, 3 of the first with rows 0, 2 of the
+        // second; lanes 32-63 with lanes 0-31): both start as v, afterwards one holds the lane's own value and the other
+        // its partner's.  As instructions: the clang builtins of this toolchain lose the second operand (verified on
+        // the GPU); the s_nops cover the wait states around a cross-lane read of a just-written register.
+        static_assert(O == 16 || O == 32, "slot strides are 8, 16, 32 lanes");
+        unsigned x = a, y = a;
+        if constexpr (O == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+        return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    }
+}
+template <int O>
+__device__ static inline void eh_merge_stage(f32x2 (&acc)[EH_CPL / 2], float& lsum) {
+    lsum = eh_xor_sum<O>(lsum);
+#pragma unroll
+    for (int d = 0; d < EH_CPL / 2; ++d) { acc[d][0] = eh_xor_sum<O>(acc[d][0]); acc[d][1] = eh_xor_sum<O>(acc[d][1]); }
+}
+// merge the softmax states of the slots (all lanes end with the merged state).  The slots of a head share their
+// reference m (eh_walk_step moves it for all of them together), so the merge is a sum of the weighted sums and of the
+// weight totals - no rescale factors.
 template <int HEADS>
 __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m, float& lsum) {
-#pragma unroll
-    for (int o = EH_LG * HEADS; o < 64; o <<= 1) {
-        const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(lsum, o);
-        const float mm = fmaxf(m, m2);
-        const float s1 = eh_exp2(m - mm), s2 = eh_exp2(m2 - mm);
-        lsum = lsum * s1 + l2 * s2;
-#pragma unroll
-        for (int d = 0; d < EH_CPL / 2; ++d) {
-            const float a0 = __shfl_xor(acc[d][0], o), a1 = __shfl_xor(acc[d][1], o);
-            acc[d][0] = acc[d][0] * s1 + a0 * s2;
-            acc[d][1] = acc[d][1] * s1 + a1 * s2;
-        }
-        m = mm;
-    }
+    (void)m;
+    constexpr int O0 = EH_LG * HEADS;
+    if constexpr (O0 <= 8) eh_merge_stage<8>(acc, lsum);
+    if constexpr (O0 <= 16) eh_merge_stage<16>(acc, lsum);
+    if constexpr (O0 <= 32) eh_merge_stage<32>(acc, lsum);
 }
 
 // Heavy rows: ONE WAVE per row, and one wave per BLOCK: the rows differ widely in length (49 .. 350
