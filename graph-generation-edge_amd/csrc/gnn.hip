@@ -379,6 +379,55 @@ __device__ static inline void eh_compact_body(const edgehip_layout& L, const int
     __syncthreads();
     // connected nodes first, then the class representatives (each group in ascending node order): tiles are
     // then either all-connected or all-isolated but one, and an all-isolated tile skips the attention phases
+    if (n <= 256 * EH_CREG) {
+        // Every node of the graph sits in a register of some thread: both groups are placed behind ONE barrier (the
+        // wave totals of every 256-node chunk and group go to LDS, every thread adds up what lies before its own
+        // wave); chunk by chunk with a running offset it took three barriers per chunk and group - 30 for a polblogs
+        // graph in a kernel that is nothing but latency.
+        __shared__ __attribute__((aligned(16))) int wc[2][EH_CREG][4];
+        unsigned livebits = 0;                                   // bit c: connected and live, bit 8 + c: live representative
+#pragma unroll
+        for (int c = 0; c < EH_CREG; ++c) {
+            const int li = 256 * c + tid;
+            bool l0 = false, l1 = false;
+            if (li < n) {
+                const int i = node0 + li;
+                const int key = rkey[c], dg = rdeg[c];
+                const bool cls = dedupe && dg == 0 && key >= 0 && key < EH_CKEYS;
+                const bool live = !cls || rep[key] == li;
+                l0 = live && dg > 0; l1 = live && !(dg > 0);
+                rep_of[i] = cls ? node0 + rep[key] : i;
+            }
+            if (256 * c < n) {
+                const unsigned long long m0 = __ballot(l0), m1 = __ballot(l1);
+                if (lane == 0) { wc[0][c][wv] = __popcll(m0); wc[1][c][wv] = __popcll(m1); }
+            }
+            livebits |= (l0 ? 1u : 0u) << c | (l1 ? 1u : 0u) << (8 + c);
+        }
+        __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int c = 0; c < EH_CREG; ++c) {
+                if (256 * c >= n) break;
+                const int li = 256 * c + tid;
+                const int w0 = wc[pass][c][0], w1 = wc[pass][c][1], w2 = wc[pass][c][2], w3 = wc[pass][c][3];
+                const bool live = (livebits >> (8 * pass + c)) & 1u;
+                const unsigned long long m = __ballot(live);
+                const int off = run + (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0) + __popcll(m & ((1ull << lane) - 1ull));
+                if (live) {
+                    const int key = rkey[c];
+                    const bool cls = dedupe && rdeg[c] == 0 && key >= 0 && key < EH_CKEYS;
+                    crow[node0 + off] = node0 + li;
+                    cwgt[node0 + off] = cls ? (float)cnt[key] : 1.0f;
+                }
+                run += w0 + w1 + w2 + w3;
+            }
+        }
+        if (tid == 0) ccount[g] = run;
+        return;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         auto chunk = [&](int c, int key, int dg) {
             const int li = 256 * c + tid;

@@ -65,6 +65,57 @@ __global__ __launch_bounds__(256) void k_select(edgehip_layout L, const int32_t*
     if (x.t_out && tid == 0) x.t_out[b] = x.t;
     if (x.clear) for (int i = b * 256 + tid; i < x.clear_n; i += gridDim.x * 256) x.clear[i] = 0;
     if (tid == 0) running = 0;
+    // Graphs of up to 2 048 nodes: the flags of all 256-node chunks first, the wave totals of every chunk to LDS, ONE
+    // barrier, then every thread adds up what lies before its own wave (the chunk-by-chunk form below takes three
+    // barriers per chunk, and this launch is nothing but latency).
+    constexpr int SEL_CH = 8;
+    __shared__ int wcs[SEL_CH][4];
+    if (n <= 256 * SEL_CH) {
+        unsigned fbits = 0;
+#pragma unroll
+        for (int c = 0; c < SEL_CH; ++c) {
+            if (256 * c >= n) break;
+            const int li = 256 * c + tid;
+            int flag = 0;
+            if (li < n) {
+                int i = node0 + li;
+                if (MODE == 0) {
+                    int nt = d0[i] - deg[i];
+                    nt = nt < 0 ? 0 : (nt > nmax ? nmax : nt);
+                    const float* lp = post + ((int64_t)t * (nmax + 1) + nt) * 2;
+                    float u0, u1;
+                    if (use_rng) {
+                        eh_u4 r = eh_philox(rng.seed, (uint32_t)li, (uint32_t)(L.gid_base + b), 0u,
+                                            (uint32_t)t * 8u + EH_STREAM_NODE);
+                        u0 = eh_u24(r.x); u1 = eh_u24(r.y);
+                    } else {
+                        u0 = uniforms[2 * (int64_t)i]; u1 = uniforms[2 * (int64_t)i + 1];
+                    }
+                    flag = eh_decide(u0, u1, lp[0], lp[1], lut);
+                } else {
+                    flag = d0[i] > deg[i];   // here d0 = deg_{t-1}, deg = deg_t
+                }
+                flags[i] = (uint8_t)flag;
+            }
+            const unsigned long long m = __ballot(flag);
+            if (lane == 0) wcs[c][wv] = __popcll(m);
+            fbits |= (flag ? 1u : 0u) << c;
+        }
+        __syncthreads();
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < SEL_CH; ++c) {
+            if (256 * c >= n) break;
+            const int w0 = wcs[c][0], w1 = wcs[c][1], w2 = wcs[c][2], w3 = wcs[c][3];
+            const bool flag = (fbits >> c) & 1u;
+            const unsigned long long m = __ballot(flag);
+            const int off = run + (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0) + __popcll(m & ((1ull << lane) - 1ull));
+            if (flag) act_nodes[node0 + off] = node0 + 256 * c + tid;
+            run += w0 + w1 + w2 + w3;
+        }
+        if (tid == 0) act_count[b] = run;
+        return;
+    }
     __syncthreads();
     for (int base = 0; base < n; base += 256) {
         int li = base + tid;
