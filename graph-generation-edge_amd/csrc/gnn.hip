@@ -1717,9 +1717,13 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane); eh_mma64(g0, am, bf);
             eh_load_frag_packed(bf, a.w_hh, 1, 2 + ct, 0, lane); eh_mma64(g0, ah, bf);
             eh_load_frag_packed(bf, a.w_hh, 1, 4 + ct, 0, lane); eh_mma64(g1, ah, bf);
+            // (both gate parts finish the GRU: each hands HALF of its tile rows to the other part through LDS - part 1
+            // its z gates and h_n terms of accumulator rows 0-7, part 0 its r gates and i_n terms of rows 8-15 - and
+            // combines the other half itself; with part 0 alone combining, half of the block's waves sat out the
+            // 16 sigmoid / tanh / blend rounds)
             const float biz = bA, bhn = bB;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + biz)));
                 xh[i * 64 + lane] = g1[i] + bhn;
             }
@@ -1727,16 +1731,36 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_load_frag_packed(bf, a.w_ih, 1, ct, 0, lane);     eh_mma64(g0, am, bf);
             eh_load_frag_packed(bf, a.w_hh, 1, ct, 0, lane);     eh_mma64(g0, ah, bf);
             eh_load_frag_packed(bf, a.w_ih, 1, 4 + ct, 0, lane); eh_mma64(g1, am, bf);
+            const float bir = bA, bin = bB;
+#pragma unroll
+            for (int i = 8; i < 16; ++i) {
+                xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + bir)));      // r gate
+                xh[i * 64 + lane] = g1[i] + bin;                           // i_n term
+            }
         }
         EH_BLOCK_SYNC();
         if (part == 0) {
             const float bir = bA, bin = bB;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 int rr = eh_crow(i, lane);
                 float zg = xz[i * 64 + lane], hn = xh[i * 64 + lane];
                 float rg = eh_sigmoid_fast(((g0[i] + bir)));
                 float ng = eh_tanh_fast((g1[i] + bin) + rg * hn);
+                float hv = hp[rr * EH_TP + col];
+                float o = (1.0f - zg) * ng + zg * hv;
+                ht[rr * EH_TP + col] = o;
+                if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
+            }
+        } else {
+            const float biz = bA, bhn = bB;
+#pragma unroll
+            for (int i = 8; i < 16; ++i) {
+                int rr = eh_crow(i, lane);
+                float rg = xz[i * 64 + lane], inn = xh[i * 64 + lane];
+                float zg = eh_sigmoid_fast(((g0[i] + biz)));
+                float hn = g1[i] + bhn;
+                float ng = eh_tanh_fast(inn + rg * hn);
                 float hv = hp[rr * EH_TP + col];
                 float o = (1.0f - zg) * ng + zg * hv;
                 ht[rr * EH_TP + col] = o;
