@@ -108,6 +108,19 @@ __device__ static inline void eh_mma64(f32x16& acc, const eh_frag3& a, const eh_
         acc = EH_MFMA_BF16(a.h[i], b.h[i], acc);
     }
 }
+// half of a 64-deep chunk: the operand groups [I0, I1) only (the loads and splits of the other groups fall away)
+template <int I0, int I1>
+__device__ static inline void eh_mma64_groups(f32x16& acc, const eh_frag3& a, const eh_frag3& b) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        acc = EH_MFMA_BF16(a.l[i], b.h[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.l[i], acc);
+        acc = EH_MFMA_BF16(a.m[i], b.m[i], acc);
+        acc = EH_MFMA_BF16(a.m[i], b.h[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.m[i], acc);
+        acc = EH_MFMA_BF16(a.h[i], b.h[i], acc);
+    }
+}
 // ---- fp32 weight tiles split while they are staged (training GEMMs: the weights change every step) -----
 // LDS image of a [32 x 64] weight tile as three bf16 planes in FRAGMENT order: dword offset of (row r, k) =
 // hh*528 + i*132 + r*4 + (k&7)/2 with hh = k>>5, i = (k&31)>>3.  A lane's operand group i is one 16-byte read

@@ -1654,13 +1654,14 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             ob0[q4] = *reinterpret_cast<const f32x4*>(a.obias0 + (size_t)g * 64 + c0 + 4 * q4);
             ob1[q4] = *reinterpret_cast<const f32x4*>(a.obias1 + (size_t)g * 64 + c0 + 4 * q4);
         }
-        constexpr int NCH = HEADS + 1, SPLIT = (NCH + 1) / 2;
-        const int ch0 = kh ? SPLIT : 0, ch1 = kh ? NCH : SPLIT;
+        // an odd number of chunks (HEADS + 1 = 9) dealt whole left one K half a product longer than the other: the
+        // middle chunk is cut in two (operand groups 0-1 to K half 0, groups 2-3 to K half 1), 4.5 products each
+        constexpr int NCH = HEADS + 1, MID = NCH / 2;
+        constexpr bool ODD = (NCH & 1) != 0;
+        const int ch0 = kh ? MID + (ODD ? 1 : 0) : 0, ch1 = kh ? NCH : MID;
         f32x16 acc = eh_zero16();
-        for (int ch = ch0; ch < ch1; ++ch) {
+        auto chunk_a = [&](int ch, eh_pfrag& af) {
             eh_frag af0;
-            eh_pfrag af, bf;
-            if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
             if (ch < HEADS) {
                 const float* p = qz + r * QP + ch * 64 + hh * 32;
 #pragma unroll
@@ -1668,9 +1669,26 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             } else {
                 eh_load_frag_lds(af0, hp, r, hh);
             }
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, ch, lane);
             eh_to_pfrag(af, af0);
+        };
+        if (ODD && kh == 1 && (MID >= HEADS || anynbr)) {
+            eh_pfrag af, bf;
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, MID, lane);
+            chunk_a(MID, af);
+            eh_mma64_groups<2, 4>(acc, af, bf);
+        }
+        for (int ch = ch0; ch < ch1; ++ch) {
+            eh_pfrag af, bf;
+            if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, ch, lane);
+            chunk_a(ch, af);
             eh_mma64(acc, af, bf);
+        }
+        if (ODD && kh == 0 && (MID >= HEADS || anynbr)) {
+            eh_pfrag af, bf;
+            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, MID, lane);
+            chunk_a(MID, af);
+            eh_mma64_groups<0, 2>(acc, af, bf);
         }
         EH_BLOCK_SYNC();                      // every wave is done reading qz
         EH_STAMP_AT(3);
