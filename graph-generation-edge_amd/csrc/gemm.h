@@ -108,6 +108,20 @@ __device__ static inline void eh_mma64(f32x16& acc, const eh_frag3& a, const eh_
         acc = EH_MFMA_BF16(a.h[i], b.h[i], acc);
     }
 }
+// two independent products side by side: their matrix instructions alternate, so neither accumulator chain waits for
+// its own previous instruction (each accumulator still sees its products in the order of eh_mma64)
+__device__ static inline void eh_mma64x2(f32x16& acc0, const eh_frag3& a0, const eh_frag3& b0,
+                                         f32x16& acc1, const eh_frag3& a1, const eh_frag3& b1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc0 = EH_MFMA_BF16(a0.l[i], b0.h[i], acc0); acc1 = EH_MFMA_BF16(a1.l[i], b1.h[i], acc1);
+        acc0 = EH_MFMA_BF16(a0.h[i], b0.l[i], acc0); acc1 = EH_MFMA_BF16(a1.h[i], b1.l[i], acc1);
+        acc0 = EH_MFMA_BF16(a0.m[i], b0.m[i], acc0); acc1 = EH_MFMA_BF16(a1.m[i], b1.m[i], acc1);
+        acc0 = EH_MFMA_BF16(a0.m[i], b0.h[i], acc0); acc1 = EH_MFMA_BF16(a1.m[i], b1.h[i], acc1);
+        acc0 = EH_MFMA_BF16(a0.h[i], b0.m[i], acc0); acc1 = EH_MFMA_BF16(a1.h[i], b1.m[i], acc1);
+        acc0 = EH_MFMA_BF16(a0.h[i], b0.h[i], acc0); acc1 = EH_MFMA_BF16(a1.h[i], b1.h[i], acc1);
+    }
+}
 // half of a 64-deep chunk: the operand groups [I0, I1) only (the loads and splits of the other groups fall away)
 template <int I0, int I1>
 __device__ static inline void eh_mma64_groups(f32x16& acc, const eh_frag3& a, const eh_frag3& b) {

@@ -1732,9 +1732,11 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         float* xz = xg + (ct * 2 + 0) * 1024;
         float* xh = xg + (ct * 2 + 1) * 1024;
         if (part == 1) {
-            eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane); eh_mma64(g0, am, bf);
+            eh_pfrag bf2;
+            eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane);
+            eh_load_frag_packed(bf2, a.w_hh, 1, 4 + ct, 0, lane);
+            eh_mma64x2(g0, am, bf, g1, ah, bf2);
             eh_load_frag_packed(bf, a.w_hh, 1, 2 + ct, 0, lane); eh_mma64(g0, ah, bf);
-            eh_load_frag_packed(bf, a.w_hh, 1, 4 + ct, 0, lane); eh_mma64(g1, ah, bf);
             // (both gate parts finish the GRU: each hands HALF of its tile rows to the other part through LDS - part 1
             // its z gates and h_n terms of accumulator rows 0-7, part 0 its r gates and i_n terms of rows 8-15 - and
             // combines the other half itself; with part 0 alone combining, half of the block's waves sat out the
@@ -1746,9 +1748,11 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 xh[i * 64 + lane] = g1[i] + bhn;
             }
         } else {
-            eh_load_frag_packed(bf, a.w_ih, 1, ct, 0, lane);     eh_mma64(g0, am, bf);
+            eh_pfrag bf2;
+            eh_load_frag_packed(bf, a.w_ih, 1, ct, 0, lane);
+            eh_load_frag_packed(bf2, a.w_ih, 1, 4 + ct, 0, lane);
+            eh_mma64x2(g0, am, bf, g1, am, bf2);
             eh_load_frag_packed(bf, a.w_hh, 1, ct, 0, lane);     eh_mma64(g0, ah, bf);
-            eh_load_frag_packed(bf, a.w_ih, 1, 4 + ct, 0, lane); eh_mma64(g1, am, bf);
             const float bir = bA, bin = bB;
 #pragma unroll
             for (int i = 8; i < 16; ++i) {
@@ -1796,13 +1800,17 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_frag t0;
             eh_load_frag_lds(t0, ht, r, hh); eh_to_pfrag(af, t0);
         }
+        f32x16 acc2[2] = {eh_zero16(), eh_zero16()};
+        {
+            eh_pfrag bf0, bf1;
+            eh_load_frag_packed(bf0, a.cw0, 1, wave * 2, 0, lane);
+            eh_load_frag_packed(bf1, a.cw0, 1, wave * 2 + 1, 0, lane);
+            eh_mma64x2(acc2[0], af, bf0, acc2[1], af, bf1);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int nt = wave * 2 + j;
-            eh_pfrag bf;
-            eh_load_frag_packed(bf, a.cw0, 1, nt, 0, lane);
-            f32x16 acc = eh_zero16();
-            eh_mma64(acc, af, bf);
+            const f32x16& acc = acc2[j];
             const int col = nt * 32 + r;
             const float cb = a.cbias[(size_t)g * 256 + col];
             float sum = 0.f;
