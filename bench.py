@@ -52,37 +52,136 @@ def parse_args():
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='NOT a measurement: all ranks share cuda:0 and talk over gloo, to exercise the multi-rank code '
                          'paths (launcher, sharding, strong-scaling leg, data-parallel training) on a one-GPU box')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='NOT a measurement: no GPU work at all; the ranks meet over gloo and print the multi-rank '
+                         'bookkeeping of the JSON line (CPU test of the launcher)')
+    ap.add_argument('--fail-rank', type=int, default=-1, help='with --dry-run-cpu: this rank exits with code 7')
     return ap.parse_args()
 
 
-def launch_ranks(n):
+def launch_ranks(n, argv=None, timeout_s=3000.0):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script as CHILD processes (one per GPU,
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relay rank 0's JSON line.  This process has
-    not touched the GPU and never does (no exec from a process that initialised it)."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                       # this exact child
-        rc = rc or p.returncode
+    not touched the GPU and never does (no exec from a process that initialised it).  All children are polled: when
+    one exits non-zero (bad device, import error) the others - which would sit in the rendezvous or a collective until
+    their own timeout - are killed and that return code is reported; a rendezvous port lost to another process between
+    the probe and rank 0's bind gets one retry on a fresh port."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+
+    def attempt():
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None))
+        # rank 0's pipes are drained by threads so that polling never blocks on them
+        import threading
+        bufs = {'out': b'', 'err': b''}
+
+        def drain(name, fh):
+            bufs[name] = fh.read()
+        readers = [threading.Thread(target=drain, args=('out', procs[0].stdout), daemon=True),
+                   threading.Thread(target=drain, args=('err', procs[0].stderr), daemon=True)]
+        for t in readers:
+            t.start()
+        deadline, rc, failed = time.time() + timeout_s, 0, None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad and failed is None:
+                failed, rc = bad[0][0], bad[0][1]
+                grace = time.time() + 5.0                     # the others usually follow by themselves
+                while time.time() < grace and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()                              # these exact children
+            if all(c is not None for c in [p.poll() for p in procs]):
+                break
+            if time.time() > deadline:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                rc = rc or 124
+            time.sleep(0.05)
+        for t in readers:
+            t.join(timeout=5.0)
+        if failed is not None:
+            sys.stderr.write(f'bench.py: rank {failed} exited with code {rc}; the remaining ranks were stopped\n')
+        return rc, bufs['out'].decode(errors='replace'), bufs['err'].decode(errors='replace')
+
+    rc, out, err = attempt()
+    if rc and ('EADDRINUSE' in err or 'address already in use' in err.lower()):
+        rc, out, err = attempt()
+    sys.stderr.write(err)
     # stdout carries the ONE JSON line; whatever else a library printed there (gloo's connection notice in a rehearsal)
     # goes to stderr
-    for line in out.decode().splitlines():
+    for line in out.splitlines():
         (sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr).write(line + '\n')
     sys.stdout.flush()
     return rc
+
+
+def certify_ranks(td, torch, device, elapsed_local, dry=False):
+    """What lets a reader of the JSON line confirm the multi-GPU run was one: the world size the process group reports,
+    every rank's (rank, host, pid, device index, device name / uuid / PCI bus id) gathered over the group itself, the
+    RCCL version torch was built against, and every rank's own elapsed time (the line's value uses the MAX)."""
+    me = {'rank': td.get_rank(), 'host': socket.gethostname(), 'pid': os.getpid(), 'elapsed_s': elapsed_local}
+    if not dry:
+        idx = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(idx)
+        me.update({'device': idx, 'name': pr.name, 'uuid': str(getattr(pr, 'uuid', '')),
+                   'pci': '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', 0),
+                                              getattr(pr, 'pci_device_id', 0)),
+                   'visible': os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES') or 'all'})
+    got = [None] * td.get_world_size()
+    td.all_gather_object(got, me)
+    out = {'world_size': td.get_world_size(), 'backend': td.get_backend(), 'ranks': got,
+           'per_rank_elapsed_s': [g['elapsed_s'] for g in got]}
+    if not dry:
+        try:
+            out['rccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:                                 # noqa: BLE001 - a missing version string is not fatal
+            out['rccl_version'] = f'unavailable ({type(e).__name__})'
+        out['distinct_devices'] = len({(g['host'], g.get('uuid') or g.get('pci'), g.get('device')) for g in got})
+    return out
+
+
+def dry_run_cpu(a):
+    """`--dry-run-cpu` (tests/test_bench_launcher.py): NOT a measurement and not the hot path - the ranks meet over gloo on
+    the CPU, skip the sampling (there is no GPU to run it on) and print the line's multi-rank bookkeeping, so the
+    launcher, the environment plumbing and the certificate can be checked without a GPU."""
+    import torch
+    import torch.distributed as td
+    from edgehip import shard
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    td.init_process_group('gloo')
+    if a.fail_rank == rank:
+        sys.exit(7)
+    total = a.total_graphs if a.total_graphs > 0 else world * a.graphs
+    gid_base, count = shard.shard_generations(total, rank, world)
+    td.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                             # stand-in for the rank's passes
+    td.barrier()
+    local = time.perf_counter() - t0
+    el = shard.max_over_ranks(local, 'cpu')
+    shards = [None] * world
+    td.all_gather_object(shards, (gid_base, count))
+    res = {'metric': 'sampled graphs/sec, polblogs 512 steps', 'value': None, 'unit': 'graphs/s', 'n_gpus': world,
+           'steps': a.steps, 'warmup': a.warmup, 'dry_run': 'no GPU work was done: launcher / process-group bookkeeping only',
+           'scaling': 'strong' if a.total_graphs > 0 else 'weak', 'elapsed_max_s': el,
+           'config': {'total_graphs_per_step': total, 'shards': shards},
+           'multi_gpu': certify_ranks(td, torch, 'cpu', local, dry=True)}
+    if rank == 0:
+        print(json.dumps(res))
+    td.destroy_process_group()
 
 
 def make_model(n, edges, device, T=T_STEPS):
@@ -138,16 +237,17 @@ def pmc_traffic():
     return None, None
 
 
-def cpu_baseline(model, n, edges, deg, budget_s=20.0):
-    """Oracle (dense-semantics torch CPU restatement of the reference) timed on this host: reverse steps
-    of ONE polblogs-shaped graph at t spread over the trajectory; graphs/s = 1 / (mean step s x 512)."""
+def cpu_baseline(model, n, edges, deg, budget_s=30.0, B=4):
+    """Oracle (dense-semantics torch CPU restatement of the reference) timed on this host, as SURVEY 8d plans it:
+    reverse steps of a batch of B = 4 polblogs-shaped graphs (the reference's polblogs batch) at t spread over the
+    trajectory; graphs/s = B / (mean step s x 512).  Bounded: 47 steps unless the budget runs out first (>= 8)."""
     import numpy as np
     import torch
     from oracle import edge_oracle as orc
     params = {k[len('_denoise_fn.'):]: v.detach().cpu() for k, v in model.state_dict().items()
               if k.startswith('_denoise_fn.')}
     o = orc.EdgeOracle(params, T_STEPS, int(deg.max()))
-    graphs = [dict(n=n, edges=edges)]
+    graphs = [dict(n=n, edges=edges)] * B
     bt = orc.make_batch(graphs)
     bt.log_node_attr = orc.index_to_log_onehot(bt.node_attr)
     bt.log_full_edge_attr = orc.index_to_log_onehot(bt.full_edge_attr)
@@ -168,15 +268,19 @@ def cpu_baseline(model, n, edges, deg, budget_s=20.0):
         if time.perf_counter() - t_start > budget_s and done >= 8:
             break
     step_s = float(np.mean(times))
-    return {'value': 1.0 / (step_s * T_STEPS), 'unit': 'graphs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{done} reverse steps (p_sample) of 1 polblogs-shaped graph at t evenly spread over '
-                      f'[0,{T_STEPS}), mean {step_s * 1e3:.0f} ms/step, extrapolated x{T_STEPS} steps'}
+    return {'value': B / (step_s * T_STEPS), 'unit': 'graphs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{done} reverse steps (p_sample) of a batch of B = {B} polblogs-shaped graphs at t evenly spread '
+                      f'over [0,{T_STEPS}) (states drawn by forward noising of the true graph), mean '
+                      f'{step_s * 1e3:.0f} ms per step of the batch; graphs/s = B / (step x {T_STEPS}): an extrapolation '
+                      f'from {done} of the {T_STEPS} steps, not a whole trajectory'}
 
 
 def main():
     a = parse_args()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus))
+    if a.dry_run_cpu:
+        return dry_run_cpu(a)
 
     import numpy as np
     import torch
@@ -222,12 +326,13 @@ def main():
         for i in range(steps):
             out = model.sample_batch(batch, seed=seed0 + i, parts=parts) if count else None
         barrier()
-        el = edgehip.shard.max_over_ranks(time.perf_counter() - t0, device)
-        return el, batch, parts, out
+        mine = time.perf_counter() - t0
+        el = edgehip.shard.max_over_ranks(mine, device)
+        return el, batch, parts, out, mine
 
     strong = a.total_graphs > 0
     total = a.total_graphs if strong else world * a.graphs
-    elapsed, batch, parts, out = timed(total, a.steps, a.warmup, a.parts, 1000)
+    elapsed, batch, parts, out, elapsed_local = timed(total, a.steps, a.warmup, a.parts, 1000)
     B = batch.num_graphs
     edges_out = int(out._slice_dict['edge_index'][-1].item()) if out is not None else 0
     value = total * a.steps / elapsed
@@ -247,13 +352,24 @@ def main():
     if a.rehearse_on_one_gpu:
         res['rehearsal'] = 'all ranks on cuda:0 over gloo: exercises the multi-rank code paths, the numbers mean nothing'
 
+    if dist:
+        # the run certifies itself: world size, devices and per-rank times as the process group saw them
+        res['multi_gpu'] = certify_ranks(td, torch, device, elapsed_local)
     if dist and not strong:
         # BASELINE config 3 as written: the 64 generations of ONE sampling run split over the ranks (64/N each)
-        sel, sb, sparts, _ = timed(64, max(1, min(a.steps, 3)), 1, a.parts, 5000)
         ssteps = max(1, min(a.steps, 3))
+        sel, sb, sparts, _, smine = timed(64, ssteps, 1, a.parts, 5000)
+        per_rank = [None] * world
+        td.all_gather_object(per_rank, smine)
         res['strong_scaling'] = {'total_graphs_per_step': 64, 'graphs_per_gpu': sb.num_graphs, 'streams_per_gpu': sparts,
                                  'value': 64 * ssteps / sel, 'unit': 'graphs/s', 'steps': ssteps,
-                                 'ms_per_step': 1e3 * sel / ssteps}
+                                 'ms_per_step': 1e3 * sel / ssteps, 'per_rank_elapsed_s': per_rank}
+    elif dist:
+        # --total-graphs: the line itself IS the strong-scaling point; the block repeats it in the same shape
+        res['strong_scaling'] = {'total_graphs_per_step': total, 'graphs_per_gpu': B, 'streams_per_gpu': parts,
+                                 'value': value, 'unit': 'graphs/s', 'steps': a.steps,
+                                 'ms_per_step': 1e3 * elapsed / a.steps,
+                                 'per_rank_elapsed_s': res['multi_gpu']['per_rank_elapsed_s']}
 
     if not a.no_roofline and B > 0 and rank == 0:
         # One more pass of the same workload with HIP events around every launch (on the launch stream) and the

@@ -818,17 +818,7 @@ __device__ static inline void eh_store_cpl_scaled(float* __restrict__ p, const f
 // Lists hold BYTE offsets of the neighbour rows (id * 256): the gather is `base + offset` with a 32-bit
 // offset (scalar base, no 64-bit address arithmetic per visit).
 __device__ static inline void eh_gather(eh_xr& x, const float* __restrict__ hsrc, uint32_t row_off, int c) {
-#if defined(EH_EXP_NOLOAD)      // timing experiments only (wrong results)
-#pragma unroll
-    for (int i = 0; i < EH_CPL / 2; ++i) x.p[i] = f32x2{__uint_as_float(row_off + i), __uint_as_float(row_off ^ (uint32_t)c)};
-#elif defined(EH_EXP_FIXEDROW)
-    eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + ((row_off & 0x300u) + (uint32_t)c * (EH_CPL * 4u))));
-#elif defined(EH_EXP_HALFLOAD)      // half the bytes through the vector L1
-    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u)));
-    x.p[0] = f32x2{a[0], a[1]}; x.p[1] = f32x2{a[2], a[3]}; x.p[2] = f32x2{a[1], a[0]}; x.p[3] = f32x2{a[3], a[2]};
-#else
     eh_load_cpl(x.p, reinterpret_cast<const float*>(reinterpret_cast<const char*>(hsrc) + (row_off + (uint32_t)c * (EH_CPL * 4u))));
-#endif
 }
 
 // The walk keeps its scores in the log2 domain: qt rows are multiplied by log2(e) once per target, so every
@@ -874,15 +864,6 @@ template <int HEADS>
 __device__ static inline void eh_walk_step(const f32x2 (&q)[EH_CPL / 2], const eh_xr (&x)[eh_walk_cfg<HEADS>::U], int nvalid,
                                            int slot, f32x2 (&acc)[EH_CPL / 2], float& m, float& mthr, float& lsum) {
     constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U, UN = eh_walk_cfg<HEADS>::UN;
-#ifdef EH_EXP_NOCOMPUTE         // timing experiment only: consume the loads, skip the softmax arithmetic
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        acc[0] += x[u].p[0] + x[u].p[2];
-        acc[1] += x[u].p[1] + x[u].p[3];
-    }
-    lsum = 1.f;
-    return;
-#endif
     float sc[U];
     float mn = m;
     if constexpr (U == 4 && NSLOT == 1 && EH_LG == 8) {
@@ -1150,8 +1131,13 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
     // XCD ownership: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the heavy rows of ITS graphs
     // (eh_xcd_of_graph: contiguous ranges of B/8 graphs, the ranges k_layer's tile order gives the XCDs), so a
     // graph's h rows are gathered through one L2 only.  Affinity only; any placement is correct.
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, nloc = (gridDim.x + 7 - xcd) >> 3;   // this XCD's blocks: jb of nloc
-    const int g0 = eh_xcd_first_graph(xcd, L.num_graphs), g1 = eh_xcd_first_graph(xcd + 1, L.num_graphs);
+    // Fewer than 8 graphs: some XCD would own none and idle, so every block then takes a slice of ALL lists.
+    const bool spread = L.num_graphs < 8;
+    const int xcd = blockIdx.x & 7;
+    const int jb = spread ? (int)blockIdx.x : (int)(blockIdx.x >> 3);                           // this group's blocks: jb of nloc
+    const int nloc = spread ? (int)gridDim.x : (int)((gridDim.x + 7 - xcd) >> 3);
+    const int g0 = spread ? 0 : eh_xcd_first_graph(xcd, L.num_graphs);
+    const int g1 = spread ? L.num_graphs : eh_xcd_first_graph(xcd + 1, L.num_graphs);
     const int32_t* clong = counter + EH_HC_LONG(L.num_graphs);
     int total = 0, nlong = 0;                                         // heavy / long rows of this XCD's graphs
     for (int gg = g0; gg < g1; ++gg) { total += counter[gg]; nlong += clong[gg]; }
@@ -1235,25 +1221,6 @@ struct eh_layer_args {
     int count_rows;                                    // edgehip_prof_enable(1): add the processed rows to eh_layer_rows
 };
 
-#ifdef EH_STAMP
-// diagnostic build only (make STAMP=1): per-phase cycle sums of wave 0 of every block
-__device__ unsigned long long eh_dbg[16];
-#define EH_STAMP_AT(k) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        atomicAdd(&eh_dbg[k], t_ - t_prev); t_prev = t_; } } while (0)
-extern "C" int edgehip_debug_read(unsigned long long* out_host, int reset) {
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(eh_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(eh_dbg), z, sizeof(z)); }
-    return 0;
-}
-#define EH_SUB_BEGIN() unsigned long long t_sub = __builtin_amdgcn_s_memtime()
-#define EH_SUB_AT(k) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        atomicAdd(&eh_dbg[k], t_ - t_sub); t_sub = t_; } } while (0)
-#else
-#define EH_STAMP_AT(k) do { } while (0)
-#define EH_SUB_BEGIN() do { } while (0)
-#define EH_SUB_AT(k) do { } while (0)
-#endif
-
 // node rows the fused layer kernel actually processed (idle graphs excluded) since the last read
 __device__ unsigned long long eh_layer_rows;
 extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) {
@@ -1283,10 +1250,7 @@ template <int HEADS>
 __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a) {
     constexpr int H = HEADS * 64, QP = H + 4;
     constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
-#ifndef EH_EXP_LDS_PAD
-#define EH_EXP_LDS_PAD 0          // occupancy experiments only
-#endif
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 96 + EH_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 96];
     float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
     float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
     float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
@@ -1320,9 +1284,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     const int mydeg = a.deg[mynid];
     const int myhs = a.heavy_slot[mynid];
     if (tid < 32) dl[tid] = mydeg;                                         // visible after the first barrier
-#ifdef EH_STAMP
-    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- phase 0 loads: the h tile (full lines), in flight under the target assignment below
     f32x4 h0v[2];
@@ -1368,7 +1329,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
     }
     EH_BLOCK_SYNC();
-    EH_STAMP_AT(0);
 
     // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it
     // needs neither qt nor the attention nor the z chunks of the conv product.  Block-uniform.
@@ -1398,7 +1358,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     EH_BLOCK_SYNC();
-    EH_STAMP_AT(1);
 
     // ---- phase B: attention of the light rows, z overwrites qt.
     // A wave owns 8 targets (dealt longest-first above) and walks them as ONE flat stream of neighbour visits: the
@@ -1406,11 +1365,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
     // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
     // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
     // neighbours side by side (slots) and merges their softmax states when the target ends.
-#ifdef EH_EXP_SKIPB
-    if (anynbr && a.ldq < 0) {
-#else
     if (anynbr) {
-#endif
         constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;   // slots, rounds per step
         constexpr int UN = eh_walk_cfg<HEADS>::UN;                     // visits per step (divides EH_HEAVY_DEG)
         static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
@@ -1418,7 +1373,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         const int slot = wgrp / HEADS, head = wgrp % HEADS;
         const int grp = lane >> 3, c = lane & 7;                       // copy layout of (d): target, 8-channel chunk
         uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (8 * EH_HEAVY_DEG);
-        EH_SUB_BEGIN();
         // (b) decode the rows into ascending neighbour-id lists in LDS.  First 64 words of all 8 rows
         //     together (popcount + wave prefix sums, the 8 scans interleaved), further words row by row.
         int wdeg = 0;             // lane k < 8: neighbours of target k walked here (0: isolated or heavy)
@@ -1470,7 +1424,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             }
         }
         EH_LDS_SYNC();
-        EH_SUB_AT(8);
         // (c) the flat walk
         {
             f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
@@ -1512,11 +1465,7 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                         eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
                 }
             };
-#ifdef EH_EXP_SKIPWALK
-            if (total_steps > 0 && a.ldq < 0) {
-#else
             if (total_steps > 0) {
-#endif
                 if constexpr (HEADS >= 4) {
                 // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
                 // load instruction per four rows instead of eight per-lane gathers of the same bytes; the address
@@ -1596,7 +1545,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 }
             }
         }
-        EH_SUB_AT(10);
         // (d) targets not walked here: isolated -> z = 0, heavy -> the block-per-row kernel computed z.
         //     Group-per-target layout: lane (target grp, c) moves channels 8c..8c+7 of every head.
         {
@@ -1622,7 +1570,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
                 }
             }
         }
-        EH_SUB_AT(11);
     }
     if (HEADS >= 4 && anynbr) {
         // the walk used the h tile's LDS as its staging tiles: bring the tile back (loads in flight across the barrier)
@@ -1639,7 +1586,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     EH_BLOCK_SYNC();
-    EH_STAMP_AT(2);
 
     // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1).  wave = (column tile ct, K half kh):
     // the 2 x (HEADS+1) (column tile, 64-deep chunk) products are dealt 5/5/4/4 (HEADS = 8) and only two
@@ -1691,7 +1637,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             eh_mma64_groups<0, 2>(acc, af, bf);
         }
         EH_BLOCK_SYNC();                      // every wave is done reading qz
-        EH_STAMP_AT(3);
         float* mine = pt + wave * EH_TSZ;
 #pragma unroll
         for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_TP + r] = acc[i];
@@ -1713,7 +1658,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     EH_BLOCK_SYNC();
-    EH_STAMP_AT(4);
 
     // ---- phase D: GRU.  wave = (column tile ct, gate part): part 0 -> r and i_n, part 1 -> z and h_n
     {
@@ -1791,7 +1735,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
         }
     }
     EH_BLOCK_SYNC();
-    EH_STAMP_AT(5);
 
     // ---- phase E: context pre-activation column sums
     {
@@ -1823,7 +1766,6 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
             if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
         }
     }
-    EH_STAMP_AT(6);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -240,9 +240,19 @@ __global__ __launch_bounds__(256) void k_offsets(int B, const int32_t* __restric
     }
 }
 
+// Upper bound of the active-pair tiles of a layout (every node of every graph active).  tptr / counts->pair_tiles and
+// the tile loops of the pair kernels are 32-bit: a layout whose bound does not fit is refused by every entry point
+// that forms the offsets, instead of wrapping on the device.  20 000-node graphs: 6.25 Mi tiles each, 85 per batch.
+extern "C" int64_t edgehip_layout_pair_tile_bound(const edgehip_layout* L) {
+    if (!L || L->num_graphs < 0 || L->max_nodes < 0) return -1;
+    const int64_t n = L->max_nodes;
+    return (int64_t)L->num_graphs * ((n * (n - 1) / 2 + EDGEHIP_PAIR_TILE - 1) / EDGEHIP_PAIR_TILE + 1);
+}
+
 extern "C" int edgehip_active_offsets(const edgehip_layout* L, const int32_t* act_count, int32_t* kptr, int64_t* aptr,
                                       int32_t* tptr, edgehip_counts* counts, void* stream) {
     EH_CHECK_ARG(L && act_count && kptr && aptr && tptr && counts);
+    if (edgehip_layout_pair_tile_bound(L) > EDGEHIP_MAX_PAIR_TILES) return EDGEHIP_ERR_TOO_LARGE;
     EH_PROF(EH_K_OFFSETS, eh_stream(stream), hipLaunchKernelGGL(k_offsets, dim3(1), dim3(256), 0, eh_stream(stream), L->num_graphs, act_count, kptr, aptr, tptr,
                        counts));
     EH_LAUNCH_CHECK();

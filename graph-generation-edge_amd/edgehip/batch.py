@@ -243,6 +243,55 @@ class GraphBatch:
         return out
 
 
+def to_graph_batch(ref_batch, device='cuda', gid_base=0):
+    """A batch in the REFERENCE's layout -> GraphBatch (host side, once per batch).
+
+    `ref_batch` is what `collate_fn(preprocess(g, degree=True))` builds (datasets/data_utils.py:43-75) and what
+    `train_fn` hands to `elbo_bpd` (experiment.py:28-33): `nodes_per_graph` int64[B], `degree` [Nn] (int64 from
+    `preprocess`, fp32 from the empty-graph sampler; optional), and the x0 edges either as the dense pair state
+    `full_edge_index` int64[2,P] + `full_edge_attr` int64[P] (the fields the reference path reads) or, when those
+    are absent, as PyG's `edge_index` int64[2,2E] (both directions, global node ids).  Neither present: an empty
+    state (a sampling batch).  The dense fields are read once here and never stored."""
+    npg = torch.as_tensor(ref_batch.nodes_per_graph).cpu().long()
+    B = int(npg.numel())
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(npg, 0)
+    deg, ddt = None, None
+    d = getattr(ref_batch, 'degree', None)
+    if d is not None:
+        d = torch.as_tensor(d).cpu()
+        if int(d.numel()) != int(ptr[-1]):
+            raise ValueError(f'degree has {int(d.numel())} entries for {int(ptr[-1])} nodes')
+        ddt = np.float32 if d.dtype.is_floating_point else np.int64
+        deg = [d[int(ptr[b]):int(ptr[b + 1])].numpy() for b in range(B)]
+    fei, fea = getattr(ref_batch, 'full_edge_index', None), getattr(ref_batch, 'full_edge_attr', None)
+    ei = getattr(ref_batch, 'edge_index', None)
+    ge = None
+    if fei is not None and fea is not None:
+        fei, fea = torch.as_tensor(fei).cpu(), torch.as_tensor(fea).cpu()
+        if fei.shape[1] != int((npg * (npg - 1) // 2).sum()) or fea.shape[0] != fei.shape[1]:
+            raise ValueError('full_edge_index / full_edge_attr do not have sum n(n-1)/2 entries')
+        ge = fei[:, fea.reshape(-1) > 0].t()
+    elif ei is not None:
+        ei = torch.as_tensor(ei).cpu()
+        ge = ei[:, ei[0] < ei[1]].t()
+    out = GraphBatch(npg.tolist(), degree=deg, device=device, gid_base=gid_base, degree_dtype=ddt)
+    if ge is not None:
+        ge = ge.contiguous().numpy()
+        if ge.shape[0]:
+            g0, g1 = np.searchsorted(ptr.numpy(), ge[:, 0], 'right'), np.searchsorted(ptr.numpy(), ge[:, 1], 'right')
+            if ge.min() < 0 or ge.max() >= int(ptr[-1]) or not np.array_equal(g0, g1):
+                raise ValueError('an edge leaves its graph (node ids must be global and within one graph)')
+        out.set_edges(out.adj, ge)
+        if deg is None:
+            dg = torch.empty(out.num_nodes, dtype=torch.int32, device=out.device)
+            with out._dev():
+                capi.check(capi.lib.edgehip_degree_from_adj(C_byref(out.layout), out.adj.data_ptr(), dg.data_ptr(),
+                                                            capi.stream_ptr()), 'degree_from_adj')
+            out.degree_i32, out.degree = dg, dg.long()
+    return out
+
+
 def C_byref(x):
     import ctypes
     return ctypes.byref(x)

@@ -17,7 +17,8 @@ PAIR_TILE = 32
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 _ERR = {ERR_ARG: 'bad argument', ERR_UNSUPPORTED: 'unsupported configuration', ERR_WORKSPACE: 'workspace too small',
-        ERR_LAUNCH: 'kernel launch failed', ERR_TOO_LARGE: 'input exceeds the fixed capacity of a no-allocation entry point'}
+        ERR_LAUNCH: 'kernel launch failed', ERR_TOO_LARGE: 'input exceeds a fixed capacity (static scratch of a no-allocation entry point, or a layout whose '
+                       '32-bit pair-tile counters could wrap: edgehip_layout_pair_tile_bound > EDGEHIP_MAX_PAIR_TILES)'}
 STATUS_CAPACITY = 1
 
 vp = C.c_void_p
@@ -144,6 +145,8 @@ def _load():
         f.restype = C.c_size_t
     lib.edgehip_version.restype = C.c_char_p
     lib.edgehip_edge_ce_loss_static_max_tiles.restype = C.c_int64
+    lib.edgehip_layout_pair_tile_bound.argtypes = [C.POINTER(Layout)]
+    lib.edgehip_layout_pair_tile_bound.restype = C.c_int64
     lib.edgehip_train_set_side_stream.argtypes = [C.c_void_p]
     lib.edgehip_train_set_side_stream.restype = C.c_int
     lib.edgehip_prof_enable.argtypes = [C.c_int]
@@ -170,9 +173,15 @@ def check(rc, what=''):
         raise EdgeHipError(f'{what}: {_ERR.get(rc, rc)} ({rc})')
 
 
-MISC_EXPORTS = ('edgehip_edge_ce_loss_static_max_tiles', 'edgehip_train_set_side_stream')
+MISC_EXPORTS = ('edgehip_edge_ce_loss_static_max_tiles', 'edgehip_train_set_side_stream', 'edgehip_layout_pair_tile_bound')
+MAX_PAIR_TILES = 1 << 29
 PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels',
                 'edgehip_prof_layer_rows')
+
+
+def edgehip_static_tiles():
+    """Capacity (pair tiles) of the static scratch of edgehip_edge_ce_loss_static."""
+    return int(lib.edgehip_edge_ce_loss_static_max_tiles())
 
 
 def prof_collect():

@@ -45,7 +45,8 @@ extern "C" {
 #define EDGEHIP_ERR_UNSUPPORTED (-2)  /* configuration outside what the kernels implement */
 #define EDGEHIP_ERR_WORKSPACE (-3)    /* workspace too small */
 #define EDGEHIP_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch */
-#define EDGEHIP_ERR_TOO_LARGE (-5)    /* input beyond the fixed capacity of an entry point that cannot allocate */
+#define EDGEHIP_ERR_TOO_LARGE (-5)    /* input beyond a fixed capacity: the static scratch of an entry point that cannot
+                                       * allocate, or a layout whose 32-bit device counters could wrap (below) */
 
 #define EDGEHIP_MAX_LAYERS 8
 #define EDGEHIP_TILE_ROWS 32          /* node tile: 32 consecutive nodes of ONE graph */
@@ -120,6 +121,15 @@ int edgehip_active_select_train(const edgehip_layout* L, const int32_t* deg_tm1,
  * ceil(A_b/32) pair tiles; totals into *counts (status is cleared). */
 int edgehip_active_offsets(const edgehip_layout* L, const int32_t* act_count, int32_t* kptr, int64_t* aptr,
                            int32_t* tptr, edgehip_counts* counts, void* stream);
+
+/* tptr / counts->pair_tiles and the tile loops of the pair kernels are 32-bit.  The reference's index lists are
+ * int64 (`nonzero`, diffusion_binomial_active.py:126-128), so there a batch is only bounded by memory; here a layout
+ * whose WORST-CASE tile count (every node of every graph active: B * (ceil(n_max(n_max-1)/2 / 32) + 1), what
+ * edgehip_layout_pair_tile_bound returns) exceeds EDGEHIP_MAX_PAIR_TILES is refused with EDGEHIP_ERR_TOO_LARGE by
+ * edgehip_active_offsets and by everything that calls it (edgehip_sample_step), before anything is launched.
+ * 20 000-node graphs: 6.25 Mi tiles each, up to 85 graphs per batch. */
+#define EDGEHIP_MAX_PAIR_TILES ((int64_t)1 << 29)
+int64_t edgehip_layout_pair_tile_bound(const edgehip_layout* L);
 
 /* ---- a10: materialise the reference's index lists ---------------------------------------
  * replaces: active_node_indices / active_edge_indices, diffusion_binomial_active.py:126-128,140-143

@@ -1,0 +1,144 @@
+"""GPU: the hand-scheduled parts of the attention walks (csrc/gnn.hip) against the oracle's attention, on inputs chosen
+to hit every code path of them.
+
+What is hand-written as instructions: the 8-head walk step's score reduction (DPP reduce-scatter ending in two
+bank-masked `v_add_f32_dpp`, eh_walk_step / eh_dpp_xor4_add), the slot merge of the 1 / 2 / 4-head walks
+(`v_permlane16_swap_b32` / `v_permlane32_swap_b32`, eh_xor_sum), and the LDS-only block barriers of the fused layer
+kernel (EH_BLOCK_SYNC).  tests/test_build_isa.py pins the instruction patterns; this file pins their RESULTS:
+
+  * ONE-layer networks, so that what comes out (the node states after the layer, `h_out` of edgehip_gnn_forward) is
+    node_in -> TransformerConv (layers.py:354) -> SiLU -> GRU of the oracle with nothing else in between, compared
+    element-wise for EVERY node at 5e-6 of the scale (the logits' 1e-4 would hide a wrong lane; 1e-4 with sharp scores);
+  * target degrees 1, 2, 3, 4, 5 (partial first step: filler visits masked), 47, 48 (the last row walked inside
+    k_layer), 49 (the first heavy row: k_attn_heavy), 128 (last non-long heavy row), 129 and 200 (long rows);
+  * every node has its own (d0, degree) pair, so no two lanes carry the same values and no row is deduplicated away;
+  * heads 8 (reduce-scatter path), 4 and 2 (lane swaps over 32 / 16+32 lanes), 1 (row rotation + both swaps);
+  * once with random-init score scales and once with query / key weights x 20 (the softmax reference moves mid-row).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import helpers as H
+from oracle import edge_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HUB_DEGREES = (1, 2, 3, 4, 5, 47, 48, 49, 128, 129, 200)
+
+
+def _hub_graph(extra_leaves=13):
+    """Hubs 0..10 with exactly HUB_DEGREES neighbours among the leaves (hub k is joined to the first d_k leaves), so
+    leaf j has as many neighbours as there are hubs with d_k > j: degrees 0 .. 11 on the leaf side."""
+    nh = len(HUB_DEGREES)
+    n = nh + max(HUB_DEGREES) + extra_leaves
+    e = [(k, nh + j) for k, d in enumerate(HUB_DEGREES) for j in range(d)]
+    return dict(n=n, edges=np.array(e, dtype=np.int64))
+
+
+def _second_graph(rng):
+    """A ragged companion so that tiles of two graphs, a tile boundary inside a graph and a short last tile occur."""
+    n = 75
+    return dict(n=n, edges=cases.random_graph(rng, n, 0.12))
+
+
+@pytest.mark.parametrize('sharp', [False, True], ids=['random_init', 'sharp_scores'])
+@pytest.mark.parametrize('heads', [8, 4, 2, 1])
+def test_one_layer_node_states_vs_oracle_on_adversarial_degrees(heads, sharp):
+    from edgehip import capi
+    from edgehip.model import _workspace
+    rng = np.random.default_rng(123)
+    graphs = [_hub_graph(), _second_graph(rng)]
+    T, t = 48, 5
+    params = orc.random_tgnn_params(60 + heads, num_heads=(heads,))
+    if sharp:
+        for k in list(params):
+            if '.lin_query.' in k or '.lin_key.' in k:
+                params[k] = params[k] * 20.0
+    # distinct target degrees: d0 = degree + 1 + (node % 7): every node can still become active, every row differs
+    degs = []
+    for g in graphs:
+        d = np.bincount(g['edges'].reshape(-1), minlength=g['n']).astype(np.int64)
+        degs.append(d + 1 + (np.arange(g['n']) % 7))
+    dmax = int(max(d.max() for d in degs))
+    ob = orc.make_batch([dict(n=g['n'], edges=g['edges'], degree=d) for g, d in zip(graphs, degs)])
+    ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+    ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+    ob.log_full_edge_attr_t = ob.log_full_edge_attr.clone()              # x_t = the graph itself: the degrees above, exactly
+    Nn = ob.num_nodes
+    s = orc.make_schedule(T)
+    u = cases.uniforms(rng, Nn, 2)
+    orc.p_sample_and_set_actives(s, ob, torch.full((Nn,), t), orc.UniformTape([u]))
+    assert sorted(set(ob.degree_t[:len(HUB_DEGREES)].tolist())) == sorted(HUB_DEGREES)
+    assert len(ob.active_node_indices) > 10
+    with torch.no_grad():
+        ref_logits, inter = orc.tgnn_forward(params, ob, torch.full((Nn,), t), dmax, T, (heads,), return_intermediates=True)
+    ref_h = inter['h0']
+
+    import edgehip
+    a = H.make_args(T, dmax, heads=(heads,))
+    model = edgehip.get_model(a, None)
+    model._denoise_fn.load_state_dict(params)
+    model = model.cuda().eval()
+    b = edgehip.GraphBatch([g['n'] for g in graphs], degree=degs, edges=[g['edges'] for g in graphs], device='cuda')
+    model._p_sample_and_set_actives(b, t, u.cuda())
+    st, L = b._state, b.layout
+    assert np.array_equal(st['deg_t'][:Nn].cpu().numpy().astype(np.int64), ob.degree_t.numpy())
+    P, folded = model._denoise_fn.c_params()
+    ws = _workspace(b, P)
+    node_repr = torch.zeros((Nn + 32, 128), dtype=torch.float32, device='cuda')
+    h_out = torch.full((Nn, 64), float('nan'), dtype=torch.float32, device='cuda')
+    capi.check(capi.lib.edgehip_gnn_forward(
+        C.byref(L), C.byref(P), folded.data_ptr(), b.adj.data_ptr(), st['deg_t'].data_ptr(), b.degree_i32.data_ptr(),
+        st['t_graph'].data_ptr(), 0, st['flags'].data_ptr(), st['act_nodes'].data_ptr(), st['kptr'].data_ptr(),
+        st['counts'].data_ptr(), node_repr.data_ptr(), h_out.data_ptr(), ws.data_ptr(), ws.numel(), capi.stream_ptr()),
+        'gnn_forward')
+    got = h_out.cpu().double()
+    assert bool(torch.isfinite(got).all())
+    scale = float(ref_h.abs().max())
+    err = (got - ref_h.double()).abs()
+    worst = int(err.max(dim=1).values.argmax())
+    # sharp scores reach ~100 units: one fp32 ulp of such a score (7.6e-6) is already a 7.6e-6 relative error of its
+    # softmax weight, in the oracle as much as here - the bound follows the scores' magnitude
+    tol = 1e-4 if sharp else 5e-6
+    assert float(err.max()) <= tol * scale, (f'node {worst} (degree {int(ob.degree_t[worst])}): '
+                                             f'{float(err.max()):.3e} vs scale {scale:.3e}')
+    # and the product path proper (live-row compaction on, active pairs only): logits
+    _, logits = model._denoise_fn(b, torch.full((Nn,), t, device='cuda'), None)
+    H.check_logits(logits, ref_logits, 1e-4)
+
+
+def test_two_layer_mixed_heads_on_adversarial_degrees():
+    """heads (8, 1) and (1, 8): the second layer's walk reads the first layer's output rows; logits vs the oracle."""
+    rng = np.random.default_rng(321)
+    graphs = [_hub_graph(extra_leaves=40), _second_graph(rng)]
+    T, t = 48, 7
+    for heads in ((8, 1), (1, 8), (4, 2)):
+        params = orc.random_tgnn_params(90 + heads[0], num_heads=heads)
+        dmax = cases.max_degree_of(graphs) + 8
+        ob = orc.make_batch(graphs)
+        ob.degree = ob.degree + 1 + (torch.arange(ob.num_nodes) % 5).float()
+        ob.log_node_attr = orc.index_to_log_onehot(ob.node_attr)
+        ob.log_full_edge_attr = orc.index_to_log_onehot(ob.full_edge_attr)
+        ob.log_full_edge_attr_t = ob.log_full_edge_attr.clone()
+        Nn = ob.num_nodes
+        u = cases.uniforms(rng, Nn, 2)
+        orc.p_sample_and_set_actives(orc.make_schedule(T), ob, torch.full((Nn,), t), orc.UniformTape([u]))
+        assert len(ob.active_edge_indices) > 50
+        with torch.no_grad():
+            ref = orc.tgnn_forward(params, ob, torch.full((Nn,), t), dmax, T, heads)
+        import edgehip
+        model = edgehip.get_model(H.make_args(T, dmax, heads=heads), None)
+        model._denoise_fn.load_state_dict(params)
+        model = model.cuda().eval()
+        npg = [g['n'] for g in graphs]
+        ptr = np.concatenate([[0], np.cumsum(npg)])
+        dd = ob.degree.numpy()
+        b = edgehip.GraphBatch(npg, degree=[dd[ptr[k]:ptr[k + 1]] for k in range(len(npg))],
+                               edges=[g['edges'] for g in graphs], device='cuda')
+        model._p_sample_and_set_actives(b, t, u.cuda())
+        _, logits = model._denoise_fn(b, torch.full((Nn,), t, device='cuda'), None)
+        H.check_logits(logits, ref, 1e-4, what=f'heads {heads}')

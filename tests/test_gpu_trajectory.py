@@ -129,7 +129,13 @@ def test_polblogs_trajectory_replay_against_the_reference():
 
 def test_polblogs_trajectory_through_the_fused_step_equals_the_reference():
     """The same 512 steps through edgehip_sample_step (the entry point the sampler and bench.py run: one call per
-    step, no host sync), uniforms supplied: per-step edge counts and the final edge list equal the reference's."""
+    step, no host sync), uniforms supplied: per-step edge counts and the final edge list equal the reference's.
+
+    This run is FREE (no re-synchronisation), so it holds only while no decision's margin is inside the fp32 rounding
+    noise of the logits (~2e-7; the smallest reference margin on this trajectory is 4.5e-6).  A kernel change that
+    reorders a sum can legitimately flip a near-tie: a mismatch is a failure only if the closest reference decision of
+    the first differing step has a margin above 1e-4 - otherwise the test skips and points at the replay test above,
+    which re-synchronises and checks each differing decision's margin."""
     import ctypes as C
     from edgehip import capi
     from edgehip.model import _state, _workspace
@@ -150,6 +156,14 @@ def test_polblogs_trajectory_through_the_fused_step_equals_the_reference():
     b.adj.zero_()
     dummy = torch.zeros((1, 2), dtype=torch.float32, device='cuda')
     keep = []
+
+    def mismatch(s, what):
+        """s: the first step whose outcome differs (the state is compared after EVERY step)."""
+        tight = float(abs(g['min_margin'][s])) if int(g['A'][s]) else float('inf')
+        if tight < 1e-4:
+            pytest.skip(f'{what}: the closest reference decision of this step has margin {tight:.2e} - a near-tie may '
+                        'have flipped; test_polblogs_trajectory_replay_against_the_reference decides')
+        pytest.fail(f'{what} (closest reference margin of the step {tight:.2e}: not a near-tie)')
     for s, t in enumerate(range(T - 1, -1, -1)):
         u_act = cases.uniforms(rng, Nn, 2).cuda()
         A = int(g['A'][s])
@@ -162,10 +176,13 @@ def test_polblogs_trajectory_through_the_fused_step_equals_the_reference():
                                                 b.degree_i32.data_ptr(), t, tabs['post'].data_ptr(), tabs['nmax'],
                                                 u_act.data_ptr(), u_pair.data_ptr(), None, capi.ptr(tabs['lut']),
                                                 counts.data_ptr(), ws.data_ptr(), ws.numel(), capi.stream_ptr()), 'sample_step')
-        if s % 16 == 15 or t == 0:
-            c = counts.cpu().numpy()
-            assert int(c[2:4].view(np.int64)[0]) == A, f't={t}: the fused step saw a different number of active pairs'
-            _, sl = b.extract_edges()
-            assert int(sl[-1]) == int(g['E'][s]), f't={t}'
+        # compared after every step: the first differing step names the decisions to look at
+        c = counts.cpu().numpy()
+        if int(c[2:4].view(np.int64)[0]) != A:
+            mismatch(s, f't={t}: the fused step saw a different number of active pairs')
+        _, sl = b.extract_edges()
+        if int(sl[-1]) != int(g['E'][s]):
+            mismatch(s, f't={t}: edge count differs')
     ei, _ = b.extract_edges()
-    assert np.array_equal(ei.cpu().numpy(), g['edge_index'])
+    if not np.array_equal(ei.cpu().numpy(), g['edge_index']):
+        pytest.fail('final edge list differs although every per-step edge count matched')

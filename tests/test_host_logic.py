@@ -187,3 +187,22 @@ def test_empty_graph_sampler_draws_like_the_reference_under_a_seed():
         assert np.array_equal(b.edges_per_graph.numpy(), g['edges_per_graph_' + tag])
         assert str(b.degree.dtype) == str(g['degree_dtype']) and np.array_equal(b.degree.numpy(), g['degree_' + tag])
         assert b.num_graphs == k and int(b.adj.abs().sum()) == 0                   # x_T input: empty graphs
+
+
+def test_pair_tile_bound_refuses_layouts_that_could_wrap_the_32_bit_counters():
+    """include/edgehip.h: tptr / counts->pair_tiles are int32; the offsets entry point refuses a layout whose worst-case
+    tile count exceeds EDGEHIP_MAX_PAIR_TILES on the HOST, before any launch (so this runs without a GPU)."""
+    import ctypes as C
+    from edgehip import capi
+    n = 20000
+    per = (n * (n - 1) // 2 + capi.PAIR_TILE - 1) // capi.PAIR_TILE + 1
+    L = capi.Layout()
+    L.num_graphs, L.max_nodes = 86, n
+    assert capi.lib.edgehip_layout_pair_tile_bound(C.byref(L)) == 86 * per > capi.MAX_PAIR_TILES
+    junk = (C.c_int64 * 4)()
+    p = C.cast(junk, C.c_void_p)
+    assert capi.lib.edgehip_active_offsets(C.byref(L), p, p, p, p, p, None) == capi.ERR_TOO_LARGE
+    L.num_graphs = 64
+    L.max_nodes = 1222                                   # the bench's batch: 64 polblogs graphs
+    assert 0 < capi.lib.edgehip_layout_pair_tile_bound(C.byref(L)) < capi.edgehip_static_tiles()
+    assert capi.lib.edgehip_layout_pair_tile_bound(None) == -1

@@ -62,11 +62,32 @@ def _both(x):
                'edge_ce_loss')
     kl_b = torch.full((B,), -2.0, dtype=torch.float32, device=dev)
     lg_b = torch.full((max(A, 1), 2), -9.0, dtype=torch.float32, device=dev)
-    before = torch.cuda.memory_stats(dev)['allocation.all.allocated']
+    # a warm call first: the per-device address of the scratch array is resolved on the first call on a device
     capi.check(capi.lib.edgehip_edge_ce_loss_static(*common, kl_b.data_ptr(), lg_b.data_ptr(), A, s), 'edge_ce_loss_static')
-    assert torch.cuda.memory_stats(dev)['allocation.all.allocated'] == before
     torch.cuda.synchronize()
+    kl_b.fill_(-2.0); lg_b.fill_(-9.0)
+    torch.cuda.synchronize()
+    # (1) neither torch's allocator nor the DEVICE sees an allocation: free bytes as hipMemGetInfo reports them are
+    #     unchanged across the call (torch's own statistics cannot see a hipMalloc inside the library)
+    before = torch.cuda.memory_stats(dev)['allocation.all.allocated']
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    capi.check(capi.lib.edgehip_edge_ce_loss_static(*common, kl_b.data_ptr(), lg_b.data_ptr(), A, s), 'edge_ce_loss_static')
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    assert torch.cuda.memory_stats(dev)['allocation.all.allocated'] == before
     assert int(st['counts'][4].item()) == 0            # status: no capacity flag
+    # (2) the callers it is for: under HIP stream capture a hipMalloc / hipFree / synchronising call is an error (it
+    #     would invalidate the capture and the library would return a launch error); the captured call replays and
+    #     gives the same bits
+    kl_c = torch.full((B,), -3.0, dtype=torch.float32, device=dev)
+    lg_c = torch.full((max(A, 1), 2), -5.0, dtype=torch.float32, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = capi.lib.edgehip_edge_ce_loss_static(*common, kl_c.data_ptr(), lg_c.data_ptr(), A, capi.stream_ptr())
+    assert rc == capi.OK
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(kl_c, kl_b) and torch.equal(lg_c, lg_b)
     return kl_a, kl_b, lg_a[:A], lg_b[:A]
 
 

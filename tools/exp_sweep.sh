@@ -3,6 +3,8 @@
 # a given t, repeated).  An experiment build is gnn.hip compiled with extra -D switches (EH_EXP_*: timing only, wrong
 # results by construction; EH_WALK_DEPTH, EH_HEAVY_DEG, EH_HEAVY_BLOCKS, EH_PAIR_BLOCKS, EH_CPL: tunables) and linked
 # with the other objects into exp_libs/libedgehip_<NAME>.so (git-ignored); kbench picks it up through EDGEHIP_LIB.
+# Round 3: the EH_EXP_* / EH_STAMP instrumentation is no longer in csrc/gnn.hip; apply
+# tools/experiments/k_layer_timing_switches.patch to a scratch copy of it first.
 #   bash tools/exp_sweep.sh NAME [NAME ...]      (through gpurun, from the repo root)
 set -e
 for V in base "$@"; do
