@@ -2236,6 +2236,15 @@ __global__ __launch_bounds__(256) void k_pair(edgehip_layout L, eh_pair_args a) 
     }
 }
 
+// this translation unit's copy of the Gumbel transforms on the grid (edgehip_gumbel_grid, which = 1)
+EH_DEFINE_GUMBEL_GRID_KERNEL(k_gumbel_grid_gnn)
+int eh_gumbel_grid_gnn(float* exact_out, float* fast_out, int64_t k0, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gumbel_grid_gnn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, exact_out, fast_out, (long long)k0,
+                       (long long)n);
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
 static void eh_fill_pair_weights(eh_pair_args& a, const edgehip_gnn_params* P, const float* folded) {
     a.fb0 = P->final_b0; a.fw2 = P->final_w2; a.fb2 = P->final_b2; a.fw4 = P->final_w4; a.fb4 = P->final_b4;
     a.pfw2 = folded ? folded + eh_make_fold_map(P).pFw2 : nullptr;

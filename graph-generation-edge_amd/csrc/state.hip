@@ -44,6 +44,21 @@ extern "C" int edgehip_degree_from_adj(const edgehip_layout* L, const uint32_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// a3  the device's Gumbel transforms on the grid (common.h): what edgehip/tables.py compares with the host's table
+// ---------------------------------------------------------------------------------------------
+EH_DEFINE_GUMBEL_GRID_KERNEL(k_gumbel_grid_state)
+
+extern "C" int edgehip_gumbel_grid(float* exact_out, float* fast_out, int64_t k0, int64_t n, int32_t which, void* stream) {
+    EH_CHECK_ARG((exact_out || fast_out) && k0 >= 0 && n >= 0 && k0 + n <= ((int64_t)1 << 24) && (which == 0 || which == 1));
+    if (n == 0) return EDGEHIP_OK;
+    if (which == 1) return eh_gumbel_grid_gnn(exact_out, fast_out, k0, n, eh_stream(stream));
+    hipLaunchKernelGGL(k_gumbel_grid_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, eh_stream(stream), exact_out, fast_out,
+                       (long long)k0, (long long)n);
+    EH_LAUNCH_CHECK();
+    return EDGEHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // a9/a10/a11  active-node selection + stable per-graph compaction.  One 256-thread block per graph.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>   // 0: sample (posterior table + Gumbel), 1: train (deg_tm1 > deg_t)

@@ -68,6 +68,7 @@ EXPORTS = {
     'edgehip_active_offsets': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp],
     'edgehip_active_pairs_enumerate': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp],
     'edgehip_q_sample_edges': [C.POINTER(Layout), vp, vp, vp, vp, vp, vp, C.POINTER(Rng), vp, vp, vp, vp],
+    'edgehip_gumbel_grid': [vp, vp, C.c_int64, C.c_int64, C.c_int32, vp],
     'edgehip_count_edges': [C.POINTER(Layout), vp, vp, vp, vp],
     'edgehip_extract_edges': [C.POINTER(Layout), vp, vp, vp, vp, C.c_int64, vp],
     'edgehip_adj_from_edges': [C.POINTER(Layout), vp, C.c_int64, vp, vp],

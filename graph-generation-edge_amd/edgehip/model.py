@@ -302,12 +302,38 @@ def _workspace(batch, P):
 
 
 _LUT_DEV = {}
+GUMBEL_MAGIC = 0x45484750
+gumbel_patch_info = {}          # device -> dict(n, eps_fast): what the exhaustive comparison found (tests, bench)
 
 
 def _gumbel_lut(device):
+    """The `gumbel_patch` blob of include/edgehip.h for `device` (kept under the old name: every call site passes
+    tabs['lut']).  Built once per process and device: the host's g over ALL 2^24 grid points (tables.gumbel_lut, the
+    reference's own torch ops) is compared on the device with the device's `exact` transform; the blob lists the grid
+    points where they differ with the host's values, and the largest |fast - host|.  64 MB cross the bus once, three
+    64 MB temporaries live for the comparison; what stays resident is 16 bytes + 8 bytes per differing point."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
     key = str(device)
     if key not in _LUT_DEV:
-        _LUT_DEV[key] = tables.gumbel_lut().to(device)
+        with torch.cuda.device(device):
+            host = tables.gumbel_lut().to(device)
+            exact, fast = torch.empty_like(host), torch.empty_like(host)
+            capi.check(capi.lib.edgehip_gumbel_grid(exact.data_ptr(), fast.data_ptr(), 0, host.numel(), 0,
+                                                    capi.stream_ptr()), 'gumbel_grid')
+            keys = (exact != host).nonzero().flatten()
+            eps = float((fast - host).abs().max().item())
+            if not (eps == eps and eps < 1e30):
+                eps = 1e30                                  # a broken fast path only means every decision takes the exact one
+            n = int(keys.numel())
+            blob = torch.zeros(4 + 2 * n, dtype=torch.int32, device=device)
+            blob[0], blob[1] = GUMBEL_MAGIC, n
+            blob[2:3] = torch.tensor([eps], dtype=torch.float32, device=device).view(torch.int32)
+            blob[4:4 + n] = keys.to(torch.int32)
+            blob[4 + n:] = host[keys].view(torch.int32)
+            gumbel_patch_info[key] = dict(n=n, eps_fast=eps, bytes=int(blob.numel()) * 4)
+            _LUT_DEV[key] = blob.view(torch.float32)
     return _LUT_DEV[key]
 
 

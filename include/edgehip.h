@@ -100,14 +100,36 @@ int edgehip_degree_from_adj(const edgehip_layout* L, const uint32_t* adj, int32_
  * n = max(d0 - deg, 0); log-probs = post_table[t_graph[b]][n] (host-built with the reference's
  * exact torch op sequence, [T][nmax+1][2] fp32); node i is active iff
  * g(u[i][1]) + lp1 > g(u[i][0]) + lp0, g(u) = -log(-log(u+1e-30)+1e-30).
- * uniforms: [Nn,2] fp32, or NULL to use `rng` (stream 0).  gumbel_lut: NULL, or the 2^24-entry
- * table of g(k*2^-24) built by the host libm (bit-exact decisions against a CPU reference).
+ * uniforms: [Nn,2] fp32, or NULL to use `rng` (stream 0).  gumbel_patch: NULL, or the patch blob described
+ * under edgehip_gumbel_grid below (decisions bit-identical to a CPU reference for every u on the 2^-24 grid).
  * Outputs: flags[Nn] (0/1); act_nodes[Nn]: graph b's active nodes, ascending, as global ids in
  * act_nodes[node_ptr[b] ...]; act_count[B]. */
 int edgehip_active_select_sample(const edgehip_layout* L, const int32_t* d0, const int32_t* deg,
                                  const int32_t* t_graph, const float* post_table, int32_t nmax,
-                                 const float* uniforms, const edgehip_rng* rng, const float* gumbel_lut,
+                                 const float* uniforms, const edgehip_rng* rng, const float* gumbel_patch,
                                  uint8_t* flags, int32_t* act_nodes, int32_t* act_count, void* stream);
+
+/* ---- a3: the Gumbel transform of every random decision -----------------------------------
+ * replaces: log_sample_categorical, diffusion/diffusion_base.py:175-180 (gumbel_noise = -log(-log(u+1e-30)+1e-30))
+ * Every decision of the path is g(u1) + lp1 > g(u0) + lp0 in fp32 (ties -> class 0, torch.argmax).  The host's g is
+ * its math library's, within an ulp of the correctly rounded value but not always equal to it, so a device
+ * logarithm alone cannot reproduce a CPU run's near-ties.  fp32 uniforms from torch.rand (and from edgehip_rng) lie
+ * on the grid k 2^-24: rounds 1-2 shipped the host's g at all 2^24 grid points (64 MB, one cache line fetched per
+ * decision).  Now g is ARITHMETIC on the device plus a small patch list:
+ *   edgehip_gumbel_grid evaluates, for u = (k0 + i) 2^-24, i < n, the device's two forms of g - `exact` (both
+ *   logarithms in fp64, rounded to fp32) and `fast` (two hardware log2) - into exact_out / fast_out (either may be
+ *   NULL).  `which` selects the copy compiled into the active-selection / forward-noising kernels (0) or the one in
+ *   the pair kernel (1); they are the same instructions and a test shows them equal.
+ *   The caller (edgehip/tables.py, once per process and device) compares `exact` with the host's own table over
+ *   ALL 2^24 points and builds the blob the `gumbel_patch` arguments take: 32-bit words [0] 0x45484750, [1] n,
+ *   [2] eps_fast = max |fast - host| over the grid (float), [3] 0, then n ascending keys k with exact != host and
+ *   the n host values (float).  n depends on the host's math library: 15 862 (127 KB) where torch's MKL runs its
+ *   Intel code path, 2 380 501 (19 MB) on an AMD EPYC host (MKL's generic path is one ulp off the correctly rounded
+ *   fp32 logarithm at 7.5 % of the grid); the list is only read at near-ties.
+ * A decision uses `fast`; if |a1 - a0| <= 2 eps_fast + rounding it is re-taken on the host's own values (`exact`,
+ * patched).  Both outcomes are the host's decision for every on-grid u: exhaustively by construction, not
+ * statistically.  gumbel_patch == NULL: `exact` only (device logarithms; no guarantee against a CPU run). */
+int edgehip_gumbel_grid(float* exact_out, float* fast_out, int64_t k0, int64_t n, int32_t which, void* stream);
 
 /* ---- a11: active nodes in training ----------------------------------------------------
  * replaces: _q_set_actives, diffusion/diffusion_binomial_active.py:134-140
@@ -152,7 +174,7 @@ int edgehip_active_pairs_enumerate(const edgehip_layout* L, const int32_t* act_n
  * adj_tm1/adj_t must be zero-filled by the caller. */
 int edgehip_q_sample_edges(const edgehip_layout* L, const uint32_t* adj0, const int32_t* t_graph,
                            const float* q_cum, const float* q_one, const float* u_tm1, const float* u_t,
-                           const edgehip_rng* rng, const float* gumbel_lut, uint32_t* adj_tm1,
+                           const edgehip_rng* rng, const float* gumbel_patch, uint32_t* adj_tm1,
                            uint32_t* adj_t, void* stream);
 
 /* ---- a17 epilogue: edge list of the state ------------------------------------------------
@@ -233,7 +255,7 @@ int edgehip_edge_resample(const edgehip_layout* L, const edgehip_gnn_params* P, 
                           const float* node_repr, const int32_t* act_nodes, const int32_t* kptr,
                           const int64_t* aptr, const int32_t* tptr, edgehip_counts* counts,
                           const float* logits_in, int32_t logits_are_logprobs, const float* uniforms,
-                          const edgehip_rng* rng, int32_t step, const float* gumbel_lut, uint32_t* adj,
+                          const edgehip_rng* rng, int32_t step, const float* gumbel_patch, uint32_t* adj,
                           float* logits_out, uint8_t* bits_out, int64_t pair_cap, void* stream);
 
 /* ---- a18: cross-entropy of the active pairs against x_{t-1} --------------------------------
@@ -270,7 +292,7 @@ int edgehip_edge_ce_loss_static(const edgehip_layout* L, const edgehip_gnn_param
 int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_params* P, const float* folded,
                         uint32_t* adj, const int32_t* d0, int32_t t, const float* post_table, int32_t nmax,
                         const float* u_node, const float* u_pair, const edgehip_rng* rng,
-                        const float* gumbel_lut, edgehip_counts* counts, void* ws, size_t ws_bytes,
+                        const float* gumbel_patch, edgehip_counts* counts, void* ws, size_t ws_bytes,
                         void* stream);
 
 /* ---- generic fp32 MFMA linear layer (exposed for tests / composition) -----------------------
