@@ -1246,8 +1246,11 @@ extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) 
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
 #define EH_TSZ (32 * EH_TP)
 
+#ifndef EH_LAYER_ATTR
+#define EH_LAYER_ATTR
+#endif
 template <int HEADS>
-__global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a) {
+__global__ __launch_bounds__(256) EH_LAYER_ATTR void k_layer(edgehip_layout L, eh_layer_args a) {
     constexpr int H = HEADS * 64, QP = H + 4;
     constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
     __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 96];
@@ -1769,6 +1772,448 @@ __global__ __launch_bounds__(256) void k_layer(edgehip_layout L, eh_layer_args a
 }
 
 // --------------------------------------------------------------------------------------------
+// The same fused layer with EIGHT waves per tile (512 threads).  Same phases, same LDS footprint (two blocks per CU),
+// but twice the waves: four per SIMD instead of two (the 4-wave kernel sits at 1.6 resident waves per SIMD with 37 %
+// of the wave time parked on waits and barriers - it is latency-bound, and more resident waves is what hides latency),
+// and every phase of a tile is spread over twice the waves, so a tile's critical path is about half as long (what
+// bounds a small batch: 1.2 tiles per CU at 8 graphs).  The price is the register budget: 128 per lane.
+//   A  2 h column tiles over 8 waves                              (per-output sums as before)
+//   B  4 targets per wave, dealt longest-first in snake order     (per-target state only: identical per target)
+//   C  wave = (column tile, K QUARTER): the 4 (heads + 1) operand groups of the conv product are dealt evenly, nine
+//      per wave with 8 heads; the four partial tiles of an output are added as (p0 + p1) + (p2 + p3)
+//   D  wave = (gate r | z | i_n | h_n, column tile); every wave then combines 4 accumulator rows of every lane
+//   E  one context column tile per wave
+// One kernel for every batch size: a graph's result does not depend on the batch it is sampled in.
+// --------------------------------------------------------------------------------------------
+#define EH_PP 36                                   // pitch (floats) of the 32-wide partial tiles of phase C
+
+// operand group I (k = 32 * (lane >> 5) + 8 I + j) of a 64-deep chunk: A from two fp32 quads (split here), B from the
+// packed weight tile; the six products in the order of eh_mma64
+template <int I>
+__device__ static inline void eh_mma_group(f32x16& acc, const f32x4& a0, const f32x4& a1, const float* __restrict__ tile, int lane) {
+    eh_u32x4 ah, am, al;
+    unsigned ph, pm, pl;
+    eh_split_pair(a0[0], a0[1], ph, pm, pl); ah[0] = ph; am[0] = pm; al[0] = pl;
+    eh_split_pair(a0[2], a0[3], ph, pm, pl); ah[1] = ph; am[1] = pm; al[1] = pl;
+    eh_split_pair(a1[0], a1[1], ph, pm, pl); ah[2] = ph; am[2] = pm; al[2] = pl;
+    eh_split_pair(a1[2], a1[3], ph, pm, pl); ah[3] = ph; am[3] = pm; al[3] = pl;
+    const eh_u32x4* p = reinterpret_cast<const eh_u32x4*>(tile) + lane;
+    const eh_u32x4 bh = p[I * 64], bm = p[256 + I * 64], bl = p[512 + I * 64];
+    acc = EH_MFMA_BF16(al, bh, acc);
+    acc = EH_MFMA_BF16(ah, bl, acc);
+    acc = EH_MFMA_BF16(am, bm, acc);
+    acc = EH_MFMA_BF16(am, bh, acc);
+    acc = EH_MFMA_BF16(ah, bm, acc);
+    acc = EH_MFMA_BF16(ah, bh, acc);
+}
+
+template <int HEADS>
+__global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_args a) {
+    static_assert(EH_BF16X3, "the 8-wave kernel is written for the split-bf16 products");
+    constexpr int H = HEADS * 64, QP = H + 4;
+    constexpr int RMIN = 8 * 32 * EH_PP + 2 * EH_TSZ;             // partial tiles, then conv and h'
+    constexpr int R1 = (32 * QP > RMIN) ? 32 * QP : RMIN;
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 8 * 4 * EH_HEAVY_DEG + 96];
+    float* qz = lds;                    // [32][QP]       qt, then z in place               (phases A-C)
+    float* pt = lds;                    // [8][32][36]    partial tiles (ct, K quarter)     (phase C end)
+    float* xg = lds;                    // [4][2][16][64] GRU gate exchange                 (phase D)
+    float* mt = lds + 8 * 32 * EH_PP;   // [32][68]       conv
+    float* ht = mt + EH_TSZ;            // [32][68]       h'
+    float* hp = lds + R1;               // [32][68]       h (layer input / GRU hidden); the walk's staging tiles in phase B
+    int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [8 waves][4 targets][EH_HEAVY_DEG] neighbour row offsets
+    int* nl = idl + 8 * 4 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
+    float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
+    int* dl = nl + 64;                                             // [32] degree of every row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    int tile;                                                      // XCD-aware tile order, as in k_layer
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
+        tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+    }
+    const int g = L.tile_graph[tile];
+    if (eh_graph_idle(a.idle, g)) return;
+    const int cbase = L.node_ptr[g] + 32 * (tile - L.tile_ptr[g]);
+    const int rows = min(32, L.node_ptr[g] + a.ccount[g] - cbase);
+    if (rows <= 0) return;
+    if (a.count_rows && tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);
+    const int r = lane & 31, hh = lane >> 5;
+    const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
+    if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }
+    const int mydeg = a.deg[mynid];
+    const int myhs = a.heavy_slot[mynid];
+    if (tid < 32) dl[tid] = mydeg;
+
+    // ---- phase 0 loads: the h tile, one 16-byte piece per thread
+    f32x4 h0v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, (tid >> 4) & 31) * 64 + (tid & 15) * 4);
+
+    // targets: ranks 8k + w on even k, 8k + 7 - w on odd k (snake deal of the 32 walk lengths over the 8 waves)
+    const int work = (r < rows && myhs < 0) ? mydeg : 0;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int wj = __builtin_amdgcn_readlane(work, j);
+        rank += (wj > work || (wj == work && j < r)) ? 1 : 0;
+    }
+    const int perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);   // lane p: the row of rank p & 31
+    const int trow4 = __shfl(perm, 8 * (lane & 3) + ((lane & 1) ? 7 - wave : wave));   // lane k < 4: row of target k
+
+    const int node0 = L.node_ptr[g];
+    const int stride = L.adj_stride[g];
+    const uint32_t* gadj = a.adj + L.adj_ptr[g];
+    const bool mine4 = lane < 4 && trow4 < rows;
+    const int nid4 = __shfl(mynid, trow4);                                // lane k < 4: node id of target k
+    const int hs4t = __shfl(myhs, trow4), dg4t = __shfl(mydeg, trow4);
+    const int hs4 = mine4 ? hs4t : -1;
+    const int dg4 = mine4 ? dg4t : 0;
+    uint32_t fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool need = __builtin_amdgcn_readlane(dg4, k) > 0 && __builtin_amdgcn_readlane(hs4, k) < 0;
+        fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid4, k) - node0) * stride + lane] : 0u;
+    }
+
+    // ---- phase 0: h tile -> LDS
+    *reinterpret_cast<f32x4*>(hp + (tid >> 4) * EH_TP + (tid & 15) * 4) = h0v;
+    EH_BLOCK_SYNC();
+    const bool anynbr = __any(mydeg > 0);                                  // block-uniform (every wave holds all 32 rows)
+
+    // ---- phase A: qt, column tiles wave, wave + 8
+    if (anynbr && wave < 2 * HEADS) {
+        eh_frag af0;
+        eh_pfrag af;
+        eh_load_frag_lds(af0, hp, r, hh);
+        eh_to_pfrag(af, af0);
+#pragma unroll
+        for (int nt = wave; nt < 2 * HEADS; nt += 8) {
+            eh_pfrag bf;
+            eh_load_frag_packed(bf, a.Mcat, 1, nt, 0, lane);
+            f32x16 acc = eh_zero16();
+            eh_mma64(acc, af, bf);
+            const int col = nt * 32 + r;
+            const float qb = a.qbias[(size_t)g * a.ldq + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) qz[eh_crow(i, lane) * QP + col] = acc[i] + qb;
+        }
+    }
+    EH_BLOCK_SYNC();
+
+    // ---- phase B: attention of the light rows, z overwrites qt (see k_layer; four targets per wave here)
+    if (anynbr) {
+        constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;
+        constexpr int UN = eh_walk_cfg<HEADS>::UN;
+        static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
+        const int wgrp = lane / EH_LG, wc = lane % EH_LG;
+        const int slot = wgrp / HEADS, head = wgrp % HEADS;
+        uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (4 * EH_HEAVY_DEG);
+        int wdeg = 0;             // lane k < 4: neighbours of target k walked here (0: isolated or heavy)
+        int total_steps = 0;      // wave-uniform
+        {
+            int cnt[4], incl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cnt[k] = __popc(fw[k]); incl[k] = cnt[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) incl[k] = eh_wave_scan_incl(incl[k]);
+            int off = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int base = __builtin_amdgcn_readlane(incl[k], 63);
+                int pos = incl[k] - cnt[k];
+                uint32_t w = fw[k];
+                const int jb = node0 + lane * 32;
+                while (w) {
+                    if (pos < EH_HEAVY_DEG) flat[off + pos] = (uint32_t)(jb + __ffs((int)w) - 1) * 256u;
+                    ++pos;
+                    w &= w - 1;
+                }
+                if (stride > 64) {
+                    const bool need = __builtin_amdgcn_readlane(dg4, k) > 0 && __builtin_amdgcn_readlane(hs4, k) < 0;
+                    if (need) {
+                        const uint32_t* rowp = gadj + (int64_t)(__builtin_amdgcn_readlane(nid4, k) - node0) * stride;
+                        for (int w0 = 64; w0 < stride; w0 += 64) {
+                            uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+                            const int c2 = __popc(w2);
+                            int in2 = c2;
+                            in2 = eh_wave_scan_incl(in2);
+                            int p2 = base + in2 - c2;
+                            const int jb2 = node0 + (w0 + lane) * 32;
+                            while (w2) {
+                                if (p2 < EH_HEAVY_DEG) flat[off + p2] = (uint32_t)(jb2 + __ffs((int)w2) - 1) * 256u;
+                                ++p2;
+                                w2 &= w2 - 1;
+                            }
+                            base += __builtin_amdgcn_readlane(in2, 63);
+                        }
+                    }
+                }
+                base = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
+                const int padded = (base + UN - 1) / UN * UN;
+                if (base + lane < padded) flat[off + base + lane] = (uint32_t)__builtin_amdgcn_readlane(nid4, k) * 256u;   // masked filler visits
+                if (lane == k) wdeg = base;
+                off += padded;
+                total_steps += padded / UN;
+            }
+        }
+        EH_LDS_SYNC();
+        {
+            f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
+            float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
+#pragma unroll
+            for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
+            int k = -1, st = 0, nst = 0, dk = 0;
+            int krow = 0;
+            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
+            };
+            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
+            };
+            auto compute = [&](const eh_xr (&x)[U]) {
+                if (st == nst) {
+                    do {
+                        ++k;
+                        dk = __builtin_amdgcn_readlane(wdeg, k);
+                        nst = (dk + UN - 1) / UN;
+                    } while (nst == 0);
+                    st = 0;
+                    krow = __builtin_amdgcn_readlane(trow4, k);
+                    eh_load_cpl(q, qz + krow * QP + head * 64 + wc * EH_CPL);
+                    eh_scale_q_log2e(q);
+#pragma unroll
+                    for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
+                    mrun = -1e30f; lrun = 0.f; mthr = -1e30f + EH_REF_SLACK;
+                }
+                eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, mthr, lrun);
+                ++st;
+                if (st == nst) {
+                    eh_merge_slots<HEADS>(acc, mrun, lrun);
+                    if (slot == 0)
+                        eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
+                }
+            };
+            if (total_steps > 0) {
+                if constexpr (HEADS >= 4) {
+                    constexpr int NLD = UN / 4;
+                    float* stage = hp + wave * (UN * EH_SGP);              // 8 waves x 4 rows x 68 floats = the h tile's LDS exactly
+                    static_assert(8 * UN * EH_SGP <= EH_TSZ, "the staging tiles live in the h tile");
+                    const int lrow = lane >> 4, lpart = lane & 15;
+                    const int lastg = total_steps - 1;
+                    auto goffs = [&](int gs, uint32_t (&o)[NLD]) {
+                        gs = gs < lastg ? gs : lastg;
+#pragma unroll
+                        for (int i = 0; i < NLD; ++i) o[i] = flat[gs * UN + 4 * i + lrow];
+                    };
+                    auto gload = [&](const uint32_t (&o)[NLD], f32x4 (&gg)[NLD]) {
+#pragma unroll
+                        for (int i = 0; i < NLD; ++i)
+                            gg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.hprev) + (o[i] + (uint32_t)lpart * 16u));
+                    };
+                    constexpr int D = EH_WALK_DEPTH;
+                    uint32_t o[NLD];
+                    f32x4 gr[D][NLD];
+                    eh_xr x[2][U];
+                    auto advance = [&](f32x4 (&grow)[NLD], int nextoffs, eh_xr (&xn)[U]) {
+#pragma unroll
+                        for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = grow[i];
+                        __builtin_amdgcn_wave_barrier();
+                        gload(o, grow);
+                        goffs(nextoffs, o);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) eh_load_cpl(xn[u].p, stage + (u * NSLOT + slot) * EH_SGP + wc * EH_CPL);
+                        __builtin_amdgcn_wave_barrier();
+                    };
+#pragma unroll
+                    for (int j = 0; j < D; ++j) { goffs(j, o); gload(o, gr[j]); }
+                    goffs(D, o);
+                    advance(gr[0], D + 1, x[0]);
+#pragma unroll 1
+                    for (int gs = 0; gs < total_steps; gs += D) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            advance(gr[(j + 1) % D], gs + j + 2 + D, x[(j + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (gs + j < total_steps) compute(x[j & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+                    constexpr int EH_PF = 2;
+                    eh_xr xs[EH_PF][U];
+                    uint32_t on[U];
+                    const int lastg = total_steps - 1;
+#pragma unroll
+                    for (int b = 0; b < EH_PF - 1; ++b) {
+                        offs_of(b < lastg ? b : lastg, on);
+                        issue(on, xs[b]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    offs_of(EH_PF - 1 < lastg ? EH_PF - 1 : lastg, on);
+#pragma unroll 1
+                    for (int gs = 0; gs < total_steps; gs += EH_PF) {
+#pragma unroll
+                        for (int b = 0; b < EH_PF; ++b) {
+                            issue(on, xs[(b + EH_PF - 1) % EH_PF]);
+                            const int nx = gs + b + EH_PF;
+                            offs_of(nx < lastg ? nx : lastg, on);
+                            if (gs + b < total_steps) compute(xs[b]);
+                        }
+                    }
+                }
+            }
+        }
+        // targets not walked here: isolated -> z = 0, heavy -> k_attn_heavy computed z.  16 lanes per target, one 16-byte
+        // piece of every head each; all loads of a row in flight before its stores
+        {
+            const int tg = lane >> 4, c16 = lane & 15;
+            const int tdeg = __shfl(wdeg, tg);
+            const int hslot = __shfl(hs4, tg);
+            const int trow = __shfl(trow4, tg);
+            if (tdeg == 0) {
+                float* zrow = qz + trow * QP + c16 * 4;
+                f32x4 zv[HEADS];
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) zv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (hslot >= 0) {
+                    const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + c16 * 4);
+#pragma unroll
+                    for (int h = 0; h < HEADS; ++h) zv[h] = zp[h * 16];
+                }
+#pragma unroll
+                for (int h = 0; h < HEADS; ++h) *reinterpret_cast<f32x4*>(zrow + h * 64) = zv[h];
+            }
+        }
+    }
+    if (HEADS >= 4 && anynbr) {
+        // the walk used the h tile's LDS as its staging tiles: bring the tile back
+        h0v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, (tid >> 4) & 31) * 64 + (tid & 15) * 4);
+        EH_BLOCK_SYNC();                      // every wave is done with its staging tile
+        *reinterpret_cast<f32x4*>(hp + (tid >> 4) * EH_TP + (tid & 15) * 4) = h0v;
+    }
+    EH_BLOCK_SYNC();
+
+    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1); wave = (column tile ct, K quarter kq)
+    {
+        const int ct = wave & 1, kq = wave >> 1;
+        const int row = tid >> 4, c0 = (tid & 15) * 4;                 // epilogue: thread = (row, 4 columns)
+        const f32x4 ob0 = *reinterpret_cast<const f32x4*>(a.obias0 + (size_t)g * 64 + c0);
+        const f32x4 ob1 = *reinterpret_cast<const f32x4*>(a.obias1 + (size_t)g * 64 + c0);
+        constexpr int NCH = HEADS + 1;                                  // 64-deep chunks; 4 operand groups each: NCH per quarter
+        const int G0 = kq * NCH, G1 = G0 + NCH;
+        f32x16 acc = eh_zero16();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (4 * ch + 3 < G0 || 4 * ch >= G1) continue;              // wave-uniform
+            if (ch < HEADS && !anynbr) continue;                        // z = 0 for the whole tile
+            const float* ap = (ch < HEADS) ? qz + r * QP + ch * 64 + hh * 32 : hp + r * EH_TP + hh * 32;
+            const float* bt = a.Ocat + (size_t)(ct * NCH + ch) * EH_PK_TILE;
+            if (4 * ch + 0 >= G0 && 4 * ch + 0 < G1)
+                eh_mma_group<0>(acc, *reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), bt, lane);
+            if (4 * ch + 1 >= G0 && 4 * ch + 1 < G1)
+                eh_mma_group<1>(acc, *reinterpret_cast<const f32x4*>(ap + 8), *reinterpret_cast<const f32x4*>(ap + 12), bt, lane);
+            if (4 * ch + 2 >= G0 && 4 * ch + 2 < G1)
+                eh_mma_group<2>(acc, *reinterpret_cast<const f32x4*>(ap + 16), *reinterpret_cast<const f32x4*>(ap + 20), bt, lane);
+            if (4 * ch + 3 >= G0 && 4 * ch + 3 < G1)
+                eh_mma_group<3>(acc, *reinterpret_cast<const f32x4*>(ap + 24), *reinterpret_cast<const f32x4*>(ap + 28), bt, lane);
+        }
+        EH_BLOCK_SYNC();                      // every wave is done reading qz
+        float* mine = pt + wave * (32 * EH_PP);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_PP + r] = acc[i];
+        EH_BLOCK_SYNC();
+        const int ect = c0 >> 5;
+        const float* p0 = pt + ect * (32 * EH_PP) + row * EH_PP + (c0 & 31);          // quarter 0 of this column tile
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p0);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p0 + 2 * (32 * EH_PP));
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p0 + 4 * (32 * EH_PP));
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(p0 + 6 * (32 * EH_PP));
+        const bool hasnbr = dl[row] > 0;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = ((v0[e] + v1[e]) + (v2[e] + v3[e])) + ob0[e];
+            if (hasnbr) x += ob1[e];
+            v[e] = eh_silu_fast(x);
+        }
+        *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0) = v;
+    }
+    EH_BLOCK_SYNC();
+
+    // ---- phase D: GRU.  wave = (gate, column tile): r = sig(Wir m + Whr h + b), z likewise, i_n = Win m + b, h_n = Whn h + b
+    {
+        const int ct = wave & 1, gate = wave >> 1;                      // 0 r, 1 z, 2 i_n, 3 h_n
+        const int col = ct * 32 + r;
+        float bias;
+        if (gate == 0) bias = a.b_ih[col] + a.b_hh[col];
+        else if (gate == 1) bias = a.b_ih[64 + col] + a.b_hh[64 + col];
+        else if (gate == 2) bias = a.b_ih[128 + col];
+        else bias = a.b_hh[128 + col];
+        f32x16 acc = eh_zero16();
+        {
+            eh_frag t0;
+            eh_pfrag af, bf;
+            if (gate != 3) {                                            // the conv operand: r, z, i_n
+                eh_load_frag_packed(bf, a.w_ih, 1, 2 * (gate == 2 ? 2 : gate) + ct, 0, lane);
+                eh_load_frag_lds(t0, mt, r, hh); eh_to_pfrag(af, t0);
+                eh_mma64(acc, af, bf);
+            }
+            if (gate != 2) {                                            // the hidden operand: r, z, h_n (after the conv product)
+                eh_load_frag_packed(bf, a.w_hh, 1, 2 * (gate == 3 ? 2 : gate) + ct, 0, lane);
+                eh_load_frag_lds(t0, hp, r, hh); eh_to_pfrag(af, t0);
+                eh_mma64(acc, af, bf);
+            }
+        }
+        float* xo = xg + (gate * 2 + ct) * 1024;
+        if (gate < 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xo[i * 64 + lane] = eh_sigmoid_fast(acc[i] + bias);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xo[i * 64 + lane] = acc[i] + bias;
+        }
+        EH_BLOCK_SYNC();
+        // combine: wave = (4 accumulator rows ig, column tile ct) of every lane
+        const int ig = wave >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * ig + j;
+            const int rr = eh_crow(i, lane);
+            const float rg = xg[(0 * 2 + ct) * 1024 + i * 64 + lane], zg = xg[(1 * 2 + ct) * 1024 + i * 64 + lane];
+            const float inn = xg[(2 * 2 + ct) * 1024 + i * 64 + lane], hn = xg[(3 * 2 + ct) * 1024 + i * 64 + lane];
+            const float ng = eh_tanh_fast(inn + rg * hn);
+            const float hv = hp[rr * EH_TP + col];
+            const float o = (1.0f - zg) * ng + zg * hv;
+            ht[rr * EH_TP + col] = o;
+            if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
+        }
+    }
+    EH_BLOCK_SYNC();
+
+    // ---- phase E: context pre-activation column sums, one 32-column tile per wave
+    {
+        eh_pfrag af, bf;
+        {
+            eh_frag t0;
+            eh_load_frag_lds(t0, ht, r, hh); eh_to_pfrag(af, t0);
+        }
+        eh_load_frag_packed(bf, a.cw0, 1, wave, 0, lane);
+        f32x16 acc = eh_zero16();
+        eh_mma64(acc, af, bf);
+        const int col = wave * 32 + r;
+        const float cb = a.cbias[(size_t)g * 256 + col];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = eh_silu_fast(acc[i] + cb);
+            sum += wl[eh_crow(i, lane)] * v;
+        }
+        sum += __shfl_xor(sum, 32);
+        if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // Tail on the active nodes, one launch (layers.py:377-379 + the folded first layer of final_out):
 //   X = [h + ctx | emb_t(x_t) | emb_0(x_0) | emb_sel[1]]  ->  silu(No0 X)  ->  silu(No2 .)  ->  W4f .  = node_repr
 // One block per 32 rows of the compact active-node list (row R of graph g = its (R - kptr[g])-th active
@@ -1982,12 +2427,24 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
             default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
         }
+#ifndef EH_LAYER8
+#define EH_LAYER8 1
+#endif
+#if EH_LAYER8
+        switch (h) {
+            case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<8>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<4>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<2>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<1>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+        }
+#else
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
             case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(256), 0, s, *L, la)); break;
             case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<2>, dim3(NT), dim3(256), 0, s, *L, la)); break;
             default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<1>, dim3(NT), dim3(256), 0, s, *L, la)); break;
         }
+#endif
         float* t = hcur; hcur = hnext; hnext = t;
     }
     if (h_out) {
