@@ -1199,9 +1199,9 @@ __global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint3
 }
 
 // --------------------------------------------------------------------------------------------
-// Fused layer: for one node tile (32 nodes of one graph, one 256-thread block)
-//   A  qt   = Mcat h + qbias_g                      -> LDS            (MFMA, 2h column tiles over 4 waves)
-//   B  z    = attention over the bit rows           -> LDS in place   (8 targets per wave)
+// Fused layer: for one node tile (32 live nodes of one graph, one 512-thread block)
+//   A  qt   = Mcat h + qbias_g                      -> LDS            (MFMA, 2h column tiles over the 8 waves)
+//   B  z    = attention over the bit rows           -> LDS in place   (4 targets per wave)
 //   C  conv = silu(Ocat [z | h] + biases)           -> LDS            (MFMA, K split over the waves + reduce)
 //   D  h'   = GRU(conv, h)                          -> global + LDS   (MFMA, gates split over the waves)
 //   E  part = column sums of silu(Wc1 h' + cbias_g) -> global         (MFMA)
@@ -1234,558 +1234,29 @@ extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) 
 // LDS queue alone (s_waitcnt lgkmcnt(0)).  __syncthreads() is a workgroup fence + s_barrier, and for the fence hipcc
 // drains the VECTOR-memory queue too (s_waitcnt vmcnt(0)): every barrier then waits for the global stores of h' and
 // for every weight fragment or gather requested ahead, which is exactly the latency the prefetches are meant to hide.
-#ifndef EH_LDS_BARRIER
-#define EH_LDS_BARRIER 1
-#endif
-#if EH_LDS_BARRIER
 #define EH_BLOCK_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
-#define EH_BLOCK_SYNC() __syncthreads()
-#endif
 
 #define EH_TP 68            // pitch (floats) of the 64-wide LDS tiles
 #define EH_TSZ (32 * EH_TP)
 
-#ifndef EH_LAYER_ATTR
-#define EH_LAYER_ATTR
-#endif
-template <int HEADS>
-__global__ __launch_bounds__(256) EH_LAYER_ATTR void k_layer(edgehip_layout L, eh_layer_args a) {
-    constexpr int H = HEADS * 64, QP = H + 4;
-    constexpr int R1 = (32 * QP > 6 * EH_TSZ) ? 32 * QP : 6 * EH_TSZ;
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 4 * 8 * EH_HEAVY_DEG + 96];
-    float* qz = lds;                    // [32][QP]   qt, then z in place              (phases A-C)
-    float* pt = lds;                    // [4][32][68] K-split partials                (phase C end)
-    float* xg = lds;                    // [2][2][16][64] GRU gate exchange            (phase D)
-    float* mt = lds + 4 * EH_TSZ;       // [32][68]   conv
-    float* ht = lds + 5 * EH_TSZ;       // [32][68]   h'
-    float* hp = lds + R1;               // [32][68]   h (layer input / GRU hidden)
-    int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [4 waves][8 targets][EH_HEAVY_DEG] neighbour ids
-    int* nl = idl + 4 * 8 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
-    float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
-    int* dl = nl + 64;                                             // [32] degree of every row
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so XCD x gets the
-    // contiguous tile range [x*NT/8, (x+1)*NT/8) = a handful of graphs whose h rows (313 KB each) stay in
-    // that XCD's 4 MB L2 for the neighbour gathers.  Affinity only; any placement is correct.
-    int tile;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
-        tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
-    }
-    const int g = L.tile_graph[tile];
-    if (eh_graph_idle(a.idle, g)) return;
-    // the tile's rows are the LIVE rows 32j .. 32j+31 of its graph (k_compact), not 32 consecutive nodes
-    const int cbase = L.node_ptr[g] + 32 * (tile - L.tile_ptr[g]);
-    const int rows = min(32, L.node_ptr[g] + a.ccount[g] - cbase);
-    if (rows <= 0) return;
-    if (a.count_rows && tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // measurement runs only (roofline figure)
-    const int r = lane & 31, hh = lane >> 5;
-    const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
-    if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }   // visible after the first barrier
-    const int mydeg = a.deg[mynid];
-    const int myhs = a.heavy_slot[mynid];
-    if (tid < 32) dl[tid] = mydeg;                                         // visible after the first barrier
-
-    // ---- phase 0 loads: the h tile (full lines), in flight under the target assignment below
-    f32x4 h0v[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = tid + it * 256;
-        h0v[it] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, i >> 4) * 64 + (i & 15) * 4);
-    }
-
-    // A wave walks 8 of the tile's rows; its time is the SUM of their degrees, so the rows are dealt to the
-    // waves longest-first in snake order (rank the 32 walk lengths, wave w takes ranks 4k + w on even k and
-    // 4k + 3 - w on odd k).  Every wave computes the same assignment from the same registers.
-    const int work = (r < rows && myhs < 0) ? mydeg : 0;                   // heavy / absent rows are not walked here
-    int rank = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int wj = __builtin_amdgcn_readlane(work, j);
-        rank += (wj > work || (wj == work && j < r)) ? 1 : 0;
-    }
-    const int perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);   // lane p: the row of rank p & 31
-    const int trow8 = __shfl(perm, 4 * (lane & 7) + ((lane & 1) ? 3 - wave : wave));   // lane k < 8: row of target k
-
-    // bit rows of this wave's 8 attention targets; issued here so the loads fly under phases 0 and A
-    const int node0 = L.node_ptr[g];
-    const int stride = L.adj_stride[g];
-    const uint32_t* gadj = a.adj + L.adj_ptr[g];
-    const bool mine8 = lane < 8 && trow8 < rows;
-    const int nid8 = __shfl(mynid, trow8);                                // lane k < 8: node id of target k
-    const int hs8t = __shfl(myhs, trow8), dg8t = __shfl(mydeg, trow8);
-    const int hs8 = mine8 ? hs8t : -1;
-    const int dg8 = mine8 ? dg8t : 0;
-    uint32_t fw[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
-        fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid8, k) - node0) * stride + lane] : 0u;
-    }
-
-    // ---- phase 0: h tile -> LDS
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = tid + it * 256;
-        *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
-    }
-    EH_BLOCK_SYNC();
-
-    // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it
-    // needs neither qt nor the attention nor the z chunks of the conv product.  Block-uniform.
-    const bool anynbr = __any(mydeg > 0);
-
-    // ---- phase A: qt
-    if (anynbr) {
-        eh_frag af0;
-        eh_pfrag af;
-        eh_load_frag_lds(af0, hp, r, hh);
-        eh_to_pfrag(af, af0);
-        // the next weight fragment is requested before the products of the current one (the bf16 products are
-        // short: an unprefetched fragment exposes most of its L2 round trip).  Measured: phase A only; the same
-        // in phases C, D and E gave nothing (207 vs 211 us per dense launch)
-        eh_pfrag bfn;
-        eh_load_frag_packed(bfn, a.Mcat, 1, wave, 0, lane);
-#pragma unroll
-        for (int nt = wave; nt < 2 * HEADS; nt += 4) {
-            const eh_pfrag bf = bfn;
-            if (nt + 4 < 2 * HEADS) eh_load_frag_packed(bfn, a.Mcat, 1, nt + 4, 0, lane);
-            f32x16 acc = eh_zero16();
-            eh_mma64(acc, af, bf);
-            const int col = nt * 32 + r;
-            const float qb = a.qbias[(size_t)g * a.ldq + col];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) qz[eh_crow(i, lane) * QP + col] = acc[i] + qb;
-        }
-    }
-    EH_BLOCK_SYNC();
-
-    // ---- phase B: attention of the light rows, z overwrites qt.
-    // A wave owns 8 targets (dealt longest-first above) and walks them as ONE flat stream of neighbour visits: the
-    // decoded neighbour lists are concatenated in LDS (each padded to a whole step), so the gathers of the
-    // next step are in flight across target boundaries and the work of a wave is the SUM of its degrees,
-    // not 8 x the largest.  Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS
-    // neighbours side by side (slots) and merges their softmax states when the target ends.
-    if (anynbr) {
-        constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;   // slots, rounds per step
-        constexpr int UN = eh_walk_cfg<HEADS>::UN;                     // visits per step (divides EH_HEAVY_DEG)
-        static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
-        const int wgrp = lane / EH_LG, wc = lane % EH_LG;              // walk layout: (slot, head) group, channel chunk
-        const int slot = wgrp / HEADS, head = wgrp % HEADS;
-        const int grp = lane >> 3, c = lane & 7;                       // copy layout of (d): target, 8-channel chunk
-        uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (8 * EH_HEAVY_DEG);
-        // (b) decode the rows into ascending neighbour-id lists in LDS.  First 64 words of all 8 rows
-        //     together (popcount + wave prefix sums, the 8 scans interleaved), further words row by row.
-        int wdeg = 0;             // lane k < 8: neighbours of target k walked here (0: isolated or heavy)
-        int total_steps = 0;      // wave-uniform
-        {
-            int cnt[8], incl[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { cnt[k] = __popc(fw[k]); incl[k] = cnt[k]; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) incl[k] = eh_wave_scan_incl(incl[k]);
-            int off = 0;          // wave-uniform: start of target k's (padded) list
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                int base = __builtin_amdgcn_readlane(incl[k], 63);
-                int pos = incl[k] - cnt[k];
-                uint32_t w = fw[k];
-                const int jb = node0 + lane * 32;
-                while (w) {
-                    if (pos < EH_HEAVY_DEG) flat[off + pos] = (uint32_t)(jb + __ffs((int)w) - 1) * 256u;
-                    ++pos;
-                    w &= w - 1;
-                }
-                if (stride > 64) {
-                    const bool need = __builtin_amdgcn_readlane(dg8, k) > 0 && __builtin_amdgcn_readlane(hs8, k) < 0;
-                    if (need) {
-                        const uint32_t* rowp = gadj + (int64_t)(__builtin_amdgcn_readlane(nid8, k) - node0) * stride;
-                        for (int w0 = 64; w0 < stride; w0 += 64) {
-                            uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
-                            const int c2 = __popc(w2);
-                            int in2 = c2;
-                            in2 = eh_wave_scan_incl(in2);
-                            int p2 = base + in2 - c2;
-                            const int jb2 = node0 + (w0 + lane) * 32;
-                            while (w2) {
-                                if (p2 < EH_HEAVY_DEG) flat[off + p2] = (uint32_t)(jb2 + __ffs((int)w2) - 1) * 256u;
-                                ++p2;
-                                w2 &= w2 - 1;
-                            }
-                            base += __builtin_amdgcn_readlane(in2, 63);
-                        }
-                    }
-                }
-                base = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
-                const int padded = (base + UN - 1) / UN * UN;
-                if (base + lane < padded) flat[off + base + lane] = (uint32_t)__builtin_amdgcn_readlane(nid8, k) * 256u;   // masked filler visits
-                if (lane == k) wdeg = base;
-                off += padded;
-                total_steps += padded / UN;
-            }
-        }
-        EH_LDS_SYNC();
-        // (c) the flat walk
-        {
-            f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
-            float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
-#pragma unroll
-            for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
-            int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
-            int krow = 0;                               // tile row of target k
-            // the row offsets of a step are read from the LDS list one step before its gathers are issued
-            // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
-            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
-            };
-            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
-            };
-            auto compute = [&](const eh_xr (&x)[U]) {
-                if (st == nst) {                         // next target with work
-                    do {
-                        ++k;
-                        dk = __builtin_amdgcn_readlane(wdeg, k);
-                        nst = (dk + UN - 1) / UN;
-                    } while (nst == 0);
-                    st = 0;
-                    krow = __builtin_amdgcn_readlane(trow8, k);
-                    eh_load_cpl(q, qz + krow * QP + head * 64 + wc * EH_CPL);
-                    eh_scale_q_log2e(q);
-#pragma unroll
-                    for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
-                    mrun = -1e30f; lrun = 0.f; mthr = -1e30f + EH_REF_SLACK;   // finite floor: exp(-1e30 - x) = 0 and never inf - inf
-                }
-                eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, mthr, lrun);
-                ++st;
-                if (st == nst) {                         // target finished: merge the slots, write z over its qt row
-                    eh_merge_slots<HEADS>(acc, mrun, lrun);
-                    if (slot == 0)
-                        eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
-                }
-            };
-            if (total_steps > 0) {
-                if constexpr (HEADS >= 4) {
-                // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
-                // load instruction per four rows instead of eight per-lane gathers of the same bytes; the address
-                // unit was busy 59 % of this kernel).  The tile lives in the h tile's LDS (hp), which phase A has
-                // finished with and which is loaded again before phase C.  Global loads run EH_WALK_DEPTH steps
-                // ahead, their offsets one more, LDS reads one; steps past the end are skipped by predication (their
-                // clamped fetches are hits) so that the loop has ONE exit.
-                constexpr int NLD = UN / 4;
-                float* stage = hp + wave * (UN * EH_SGP);
-                const int lrow = lane >> 4, lpart = lane & 15;
-                const int lastg = total_steps - 1;
-                auto goffs = [&](int gs, uint32_t (&o)[NLD]) {
-                    gs = gs < lastg ? gs : lastg;
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) o[i] = flat[gs * UN + 4 * i + lrow];
-                };
-                auto gload = [&](const uint32_t (&o)[NLD], f32x4 (&g)[NLD]) {
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i)
-                        g[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.hprev) + (o[i] + (uint32_t)lpart * 16u));
-                };
-                constexpr int D = EH_WALK_DEPTH;
-                uint32_t o[NLD];
-                f32x4 g[D][NLD];                               // ring: rows of the next D steps, in flight
-                eh_xr x[2][U];
-                auto advance = [&](f32x4 (&gr)[NLD], int nextoffs, eh_xr (&xn)[U]) {   // gr: rows of the step after the current one
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(stage + (4 * i + lrow) * EH_SGP + lpart * 4) = gr[i];
-                    __builtin_amdgcn_wave_barrier();           // the reads below are other lanes' writes: program order
-                    gload(o, gr);                              // D steps further on
-                    goffs(nextoffs, o);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) eh_load_cpl(xn[u].p, stage + (u * NSLOT + slot) * EH_SGP + wc * EH_CPL);
-                    __builtin_amdgcn_wave_barrier();
-                };
-#pragma unroll
-                for (int j = 0; j < D; ++j) { goffs(j, o); gload(o, g[j]); }
-                goffs(D, o);
-                advance(g[0], D + 1, x[0]);                    // tile <- step 0, loads step D, reads step 0
-#pragma unroll 1
-                for (int gs = 0; gs < total_steps; gs += D) {
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        advance(g[(j + 1) % D], gs + j + 2 + D, x[(j + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (gs + j < total_steps) compute(x[j & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                } else {
-                // HEADS <= 2: a load instruction already brings 4-8 different rows (one per slot): gather directly,
-                // two register sets, the gathers one step ahead of their use
-                constexpr int EH_PF = 2;
-                eh_xr xs[EH_PF][U];
-                uint32_t on[U];
-                const int lastg = total_steps - 1;
-#pragma unroll
-                for (int b = 0; b < EH_PF - 1; ++b) {
-                    offs_of(b < lastg ? b : lastg, on);
-                    issue(on, xs[b]);
-                    __builtin_amdgcn_sched_barrier(0);     // issue order = consumption order (vmcnt counts in order)
-                }
-                offs_of(EH_PF - 1 < lastg ? EH_PF - 1 : lastg, on);
-                // ONE loop exit: with an exit inside the unrolled body the backend funnels it through the
-                // latch and then drains the whole load queue at the loop header (s_waitcnt vmcnt(1)).  The
-                // steps past the end are skipped by predication instead; their (clamped) fetches are hits.
-#pragma unroll 1
-                for (int gs = 0; gs < total_steps; gs += EH_PF) {
-#pragma unroll
-                    for (int b = 0; b < EH_PF; ++b) {
-                        issue(on, xs[(b + EH_PF - 1) % EH_PF]);
-                        const int nx = gs + b + EH_PF;
-                        offs_of(nx < lastg ? nx : lastg, on);
-                        if (gs + b < total_steps) compute(xs[b]);
-                    }
-                }
-                }
-            }
-        }
-        // (d) targets not walked here: isolated -> z = 0, heavy -> the block-per-row kernel computed z.
-        //     Group-per-target layout: lane (target grp, c) moves channels 8c..8c+7 of every head.
-        {
-            const int tdeg = __shfl(wdeg, grp);
-            const int hslot = __shfl(hs8, grp);
-            const int trow = __shfl(trow8, grp);          // outside the branch: the source lanes must be active
-            if (tdeg == 0) {
-                // every load of the row first, then the stores: written head by head, the compiler waits for
-                // each pair of heads before it requests the next (four exposed round trips per heavy row)
-                float* zrow = qz + trow * QP + c * 8;
-                f32x4 zv[2 * HEADS];
-#pragma unroll
-                for (int h = 0; h < 2 * HEADS; ++h) zv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (hslot >= 0) {
-                    const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + c * 8);
-#pragma unroll
-                    for (int h = 0; h < HEADS; ++h) { zv[2 * h] = zp[h * 16]; zv[2 * h + 1] = zp[h * 16 + 1]; }
-                }
-#pragma unroll
-                for (int h = 0; h < HEADS; ++h) {
-                    *reinterpret_cast<f32x4*>(zrow + h * 64) = zv[2 * h];
-                    *reinterpret_cast<f32x4*>(zrow + h * 64 + 4) = zv[2 * h + 1];
-                }
-            }
-        }
-    }
-    if (HEADS >= 4 && anynbr) {
-        // the walk used the h tile's LDS as its staging tiles: bring the tile back (loads in flight across the barrier)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = tid + it * 256;
-            h0v[it] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, i >> 4) * 64 + (i & 15) * 4);
-        }
-        EH_BLOCK_SYNC();                      // every wave is done with its staging tile
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = tid + it * 256;
-            *reinterpret_cast<f32x4*>(hp + (i >> 4) * EH_TP + (i & 15) * 4) = h0v[it];
-        }
-    }
-    EH_BLOCK_SYNC();
-
-    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1).  wave = (column tile ct, K half kh):
-    // the 2 x (HEADS+1) (column tile, 64-deep chunk) products are dealt 5/5/4/4 (HEADS = 8) and only two
-    // partial tiles per output meet in LDS
-    {
-        const int ct = wave & 1, kh = wave >> 1;
-        // epilogue operands requested before the products (after the barriers they would expose an L2 round trip)
-        const int row = tid >> 3, c0 = (tid & 7) * 8;
-        f32x4 ob0[2], ob1[2];
-#pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-            ob0[q4] = *reinterpret_cast<const f32x4*>(a.obias0 + (size_t)g * 64 + c0 + 4 * q4);
-            ob1[q4] = *reinterpret_cast<const f32x4*>(a.obias1 + (size_t)g * 64 + c0 + 4 * q4);
-        }
-        // an odd number of chunks (HEADS + 1 = 9) dealt whole left one K half a product longer than the other: the
-        // middle chunk is cut in two (operand groups 0-1 to K half 0, groups 2-3 to K half 1), 4.5 products each
-        constexpr int NCH = HEADS + 1, MID = NCH / 2;
-        constexpr bool ODD = (NCH & 1) != 0;
-        const int ch0 = kh ? MID + (ODD ? 1 : 0) : 0, ch1 = kh ? NCH : MID;
-        f32x16 acc = eh_zero16();
-        auto chunk_a = [&](int ch, eh_pfrag& af) {
-            eh_frag af0;
-            if (ch < HEADS) {
-                const float* p = qz + r * QP + ch * 64 + hh * 32;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af0.v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
-            } else {
-                eh_load_frag_lds(af0, hp, r, hh);
-            }
-            eh_to_pfrag(af, af0);
-        };
-        if (ODD && kh == 1 && (MID >= HEADS || anynbr)) {
-            eh_pfrag af, bf;
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, MID, lane);
-            chunk_a(MID, af);
-            eh_mma64_groups<2, 4>(acc, af, bf);
-        }
-        for (int ch = ch0; ch < ch1; ++ch) {
-            eh_pfrag af, bf;
-            if (ch < HEADS && !anynbr) continue;          // z = 0 for the whole tile
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, ch, lane);
-            chunk_a(ch, af);
-            eh_mma64(acc, af, bf);
-        }
-        if (ODD && kh == 0 && (MID >= HEADS || anynbr)) {
-            eh_pfrag af, bf;
-            eh_load_frag_packed(bf, a.Ocat, HEADS + 1, ct, MID, lane);
-            chunk_a(MID, af);
-            eh_mma64_groups<0, 2>(acc, af, bf);
-        }
-        EH_BLOCK_SYNC();                      // every wave is done reading qz
-        float* mine = pt + wave * EH_TSZ;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_TP + r] = acc[i];
-        EH_BLOCK_SYNC();
-        const float* p0 = pt + (c0 >> 5) * EH_TSZ + row * EH_TP + (c0 & 31);      // K half 0 of this column tile
-        const bool hasnbr = dl[row] > 0;
-#pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(p0 + 4 * q4);
-            const f32x4 t = *reinterpret_cast<const f32x4*>(p0 + 2 * EH_TSZ + 4 * q4);
-            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e] + ob0[q4][e];
-                if (hasnbr) x += ob1[q4][e];
-                v[e] = eh_silu_fast(x);
-            }
-            *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0 + 4 * q4) = v;
-        }
-    }
-    EH_BLOCK_SYNC();
-
-    // ---- phase D: GRU.  wave = (column tile ct, gate part): part 0 -> r and i_n, part 1 -> z and h_n
-    {
-        const int ct = wave & 1, part = wave >> 1;
-        const int col = ct * 32 + r;
-        eh_pfrag am, ah, bf;
-        {
-            eh_frag t0;
-            eh_load_frag_lds(t0, mt, r, hh); eh_to_pfrag(am, t0);
-            eh_load_frag_lds(t0, hp, r, hh); eh_to_pfrag(ah, t0);
-        }
-        f32x16 g0 = eh_zero16(), g1 = eh_zero16();
-        // gate biases requested before the products: part 1 -> (b_iz + b_hz, b_hn), part 0 -> (b_ir + b_hr, b_in)
-        const float bA = a.b_ih[(part ? 64 : 0) + col] + a.b_hh[(part ? 64 : 0) + col];
-        const float bB = part ? a.b_hh[128 + col] : a.b_ih[128 + col];
-        float* xz = xg + (ct * 2 + 0) * 1024;
-        float* xh = xg + (ct * 2 + 1) * 1024;
-        if (part == 1) {
-            eh_pfrag bf2;
-            eh_load_frag_packed(bf, a.w_ih, 1, 2 + ct, 0, lane);
-            eh_load_frag_packed(bf2, a.w_hh, 1, 4 + ct, 0, lane);
-            eh_mma64x2(g0, am, bf, g1, ah, bf2);
-            eh_load_frag_packed(bf, a.w_hh, 1, 2 + ct, 0, lane); eh_mma64(g0, ah, bf);
-            // (both gate parts finish the GRU: each hands HALF of its tile rows to the other part through LDS - part 1
-            // its z gates and h_n terms of accumulator rows 0-7, part 0 its r gates and i_n terms of rows 8-15 - and
-            // combines the other half itself; with part 0 alone combining, half of the block's waves sat out the
-            // 16 sigmoid / tanh / blend rounds)
-            const float biz = bA, bhn = bB;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + biz)));
-                xh[i * 64 + lane] = g1[i] + bhn;
-            }
-        } else {
-            eh_pfrag bf2;
-            eh_load_frag_packed(bf, a.w_ih, 1, ct, 0, lane);
-            eh_load_frag_packed(bf2, a.w_ih, 1, 4 + ct, 0, lane);
-            eh_mma64x2(g0, am, bf, g1, am, bf2);
-            eh_load_frag_packed(bf, a.w_hh, 1, ct, 0, lane);     eh_mma64(g0, ah, bf);
-            const float bir = bA, bin = bB;
-#pragma unroll
-            for (int i = 8; i < 16; ++i) {
-                xz[i * 64 + lane] = eh_sigmoid_fast(((g0[i] + bir)));      // r gate
-                xh[i * 64 + lane] = g1[i] + bin;                           // i_n term
-            }
-        }
-        EH_BLOCK_SYNC();
-        if (part == 0) {
-            const float bir = bA, bin = bB;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int rr = eh_crow(i, lane);
-                float zg = xz[i * 64 + lane], hn = xh[i * 64 + lane];
-                float rg = eh_sigmoid_fast(((g0[i] + bir)));
-                float ng = eh_tanh_fast((g1[i] + bin) + rg * hn);
-                float hv = hp[rr * EH_TP + col];
-                float o = (1.0f - zg) * ng + zg * hv;
-                ht[rr * EH_TP + col] = o;
-                if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
-            }
-        } else {
-            const float biz = bA, bhn = bB;
-#pragma unroll
-            for (int i = 8; i < 16; ++i) {
-                int rr = eh_crow(i, lane);
-                float rg = xz[i * 64 + lane], inn = xh[i * 64 + lane];
-                float zg = eh_sigmoid_fast(((g0[i] + biz)));
-                float hn = g1[i] + bhn;
-                float ng = eh_tanh_fast(inn + rg * hn);
-                float hv = hp[rr * EH_TP + col];
-                float o = (1.0f - zg) * ng + zg * hv;
-                ht[rr * EH_TP + col] = o;
-                if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
-            }
-        }
-    }
-    EH_BLOCK_SYNC();
-
-    // ---- phase E: context pre-activation column sums
-    {
-        eh_pfrag af;
-        {
-            eh_frag t0;
-            eh_load_frag_lds(t0, ht, r, hh); eh_to_pfrag(af, t0);
-        }
-        f32x16 acc2[2] = {eh_zero16(), eh_zero16()};
-        {
-            eh_pfrag bf0, bf1;
-            eh_load_frag_packed(bf0, a.cw0, 1, wave * 2, 0, lane);
-            eh_load_frag_packed(bf1, a.cw0, 1, wave * 2 + 1, 0, lane);
-            eh_mma64x2(acc2[0], af, bf0, acc2[1], af, bf1);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nt = wave * 2 + j;
-            const f32x16& acc = acc2[j];
-            const int col = nt * 32 + r;
-            const float cb = a.cbias[(size_t)g * 256 + col];
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = eh_silu_fast(acc[i] + cb);
-                sum += wl[eh_crow(i, lane)] * v;                 // weight 0 beyond the tile's rows, class size for a representative
-            }
-            sum += __shfl_xor(sum, 32);
-            if (lane < 32) a.part[(size_t)tile * 256 + col] = sum;
-        }
-    }
-}
-
 // --------------------------------------------------------------------------------------------
-// The same fused layer with EIGHT waves per tile (512 threads).  Same phases, same LDS footprint (two blocks per CU),
-// but twice the waves: four per SIMD instead of two (the 4-wave kernel sits at 1.6 resident waves per SIMD with 37 %
-// of the wave time parked on waits and barriers - it is latency-bound, and more resident waves is what hides latency),
-// and every phase of a tile is spread over twice the waves, so a tile's critical path is about half as long (what
-// bounds a small batch: 1.2 tiles per CU at 8 graphs).  The price is the register budget: 128 per lane.
-//   A  2 h column tiles over 8 waves                              (per-output sums as before)
+// EIGHT waves per tile (512 threads) and two blocks per CU: four waves per SIMD, at 128 registers per lane.  Rounds 1-2
+// ran four waves per tile (two per SIMD at ~200 registers): 1.6 resident waves per SIMD, 37 % of the wave time parked on
+// waits and barriers - latency-bound, and more resident waves is what hides latency (203 -> 163 us per dense launch,
+// SQ counters in profiles/r03_*: 3.8 waves per SIMD, vector ALU 57 % + matrix pipe 28 % busy).  The phases of a tile
+// are spread over the eight waves:
+//   A  2 h column tiles over 8 waves
 //   B  4 targets per wave, dealt longest-first in snake order     (per-target state only: identical per target)
-//   C  wave = (column tile, K QUARTER): the 4 (heads + 1) operand groups of the conv product are dealt evenly, nine
-//      per wave with 8 heads; the four partial tiles of an output are added as (p0 + p1) + (p2 + p3)
-//   D  wave = (gate r | z | i_n | h_n, column tile); every wave then combines 4 accumulator rows of every lane
+//   C  wave = K EIGHTH: the 4 (heads + 1) operand groups of the conv product are dealt evenly (4 or 5 per wave with 8
+//      heads); a wave splits its groups of [z | h] once and multiplies them into both column tiles; the eight partial
+//      tiles of an output are added as ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7))
+//   D  wave = (gate r | z | i_n | h_n, column tile); then thread = (row, 4 columns) blends, stores h' and its planes
 //   E  one context column tile per wave
+// Operands that several waves read as fragments (conv, h in the GRU, h') are split into bf16 planes once, by the thread
+// that produces them (with the per-fragment splits 37 % of the kernel's vector instructions were operand splits).
 // One kernel for every batch size: a graph's result does not depend on the batch it is sampled in.
 // --------------------------------------------------------------------------------------------
-#define EH_PP 36                                   // pitch (floats) of the 32-wide partial tiles of phase C
+#define EH_SPL (3 * EH_W3_PLANE)                   // dwords of a 32 x 64 tile kept as three bf16 planes in fragment order
 
 // operand group I (k = 32 * (lane >> 5) + 8 I + j) of a 64-deep chunk: A from two fp32 quads (split here), B from the
 // packed weight tile; the six products in the order of eh_mma64
@@ -1807,36 +1278,66 @@ __device__ static inline void eh_mma_group(f32x16& acc, const f32x4& a0, const f
     acc = EH_MFMA_BF16(ah, bh, acc);
 }
 
+// the same group multiplied into two column tiles: A is split once, the two chains alternate (neither waits for itself)
+template <int I>
+__device__ static inline void eh_mma_group2(f32x16& acc0, f32x16& acc1, const f32x4& a0, const f32x4& a1,
+                                            const float* __restrict__ tile0, const float* __restrict__ tile1, int lane) {
+    eh_u32x4 ah, am, al;
+    unsigned ph, pm, pl;
+    eh_split_pair(a0[0], a0[1], ph, pm, pl); ah[0] = ph; am[0] = pm; al[0] = pl;
+    eh_split_pair(a0[2], a0[3], ph, pm, pl); ah[1] = ph; am[1] = pm; al[1] = pl;
+    eh_split_pair(a1[0], a1[1], ph, pm, pl); ah[2] = ph; am[2] = pm; al[2] = pl;
+    eh_split_pair(a1[2], a1[3], ph, pm, pl); ah[3] = ph; am[3] = pm; al[3] = pl;
+    const eh_u32x4* p0 = reinterpret_cast<const eh_u32x4*>(tile0) + lane;
+    const eh_u32x4* p1 = reinterpret_cast<const eh_u32x4*>(tile1) + lane;
+    const eh_u32x4 bh0 = p0[I * 64], bm0 = p0[256 + I * 64], bl0 = p0[512 + I * 64];
+    const eh_u32x4 bh1 = p1[I * 64], bm1 = p1[256 + I * 64], bl1 = p1[512 + I * 64];
+    acc0 = EH_MFMA_BF16(al, bh0, acc0); acc1 = EH_MFMA_BF16(al, bh1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bl0, acc0); acc1 = EH_MFMA_BF16(ah, bl1, acc1);
+    acc0 = EH_MFMA_BF16(am, bm0, acc0); acc1 = EH_MFMA_BF16(am, bm1, acc1);
+    acc0 = EH_MFMA_BF16(am, bh0, acc0); acc1 = EH_MFMA_BF16(am, bh1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bm0, acc0); acc1 = EH_MFMA_BF16(ah, bm1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bh0, acc0); acc1 = EH_MFMA_BF16(ah, bh1, acc1);
+}
+
 template <int HEADS>
-__global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_args a) {
+__global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_args a) {
     static_assert(EH_BF16X3, "the 8-wave kernel is written for the split-bf16 products");
     constexpr int H = HEADS * 64, QP = H + 4;
-    constexpr int RMIN = 8 * 32 * EH_PP + 2 * EH_TSZ;             // partial tiles, then conv and h'
+    constexpr int RMIN = 16 * 32 * 32;                             // the 16 partial tiles of phase C
     constexpr int R1 = (32 * QP > RMIN) ? 32 * QP : RMIN;
+    static_assert(8192 + 2 * EH_SPL <= R1, "gate exchange + conv / h' planes + h planes fit behind each other");
     __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 8 * 4 * EH_HEAVY_DEG + 96];
-    float* qz = lds;                    // [32][QP]       qt, then z in place               (phases A-C)
-    float* pt = lds;                    // [8][32][36]    partial tiles (ct, K quarter)     (phase C end)
-    float* xg = lds;                    // [4][2][16][64] GRU gate exchange                 (phase D)
-    float* mt = lds + 8 * 32 * EH_PP;   // [32][68]       conv
-    float* ht = mt + EH_TSZ;            // [32][68]       h'
-    float* hp = lds + R1;               // [32][68]       h (layer input / GRU hidden); the walk's staging tiles in phase B
+    float* qz = lds;                    // [32][QP]       qt, then z in place                     (phases A-C)
+    float* pt = lds;                    // [16][32][32]   partial tiles (K eighth, column tile)   (phase C end)
+    float* xg = lds;                    // [4][2][16][64] GRU gate exchange                       (phase D)
+    // operands that several waves read as MFMA fragments are split into their three bf16 planes ONCE, by the thread that
+    // produces them, and kept in fragment order (gemm.h: eh_stage3_quad / eh_load_frag3_lds): conv, h' (over conv) and h
+    unsigned* mtl = reinterpret_cast<unsigned*>(lds + 8192);            // conv planes                (phases C end - D)
+    unsigned* htl = mtl;                                                // h' planes, over conv       (phases D end - E)
+    unsigned* hpl = reinterpret_cast<unsigned*>(lds + 8192 + EH_SPL);   // h planes                   (phase D)
+    float* hp = lds + R1;               // [32][68]       h in fp32 (phases 0, A, C, GRU blend); the walk's staging tiles in phase B
     int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [8 waves][4 targets][EH_HEAVY_DEG] neighbour row offsets
     int* nl = idl + 8 * 4 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
     float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
     int* dl = nl + 64;                                             // [32] degree of every row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    int tile;                                                      // XCD-aware tile order, as in k_layer
+    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so XCD x gets the
+    // contiguous tile range [x*NT/8, (x+1)*NT/8) = a handful of graphs whose h rows (313 KB each) stay in
+    // that XCD's 4 MB L2 for the neighbour gathers.  Affinity only; any placement is correct.
+    int tile;
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, qn = nwg >> 3, rn = nwg & 7;
         tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
     }
     const int g = L.tile_graph[tile];
     if (eh_graph_idle(a.idle, g)) return;
+    // the tile's rows are the LIVE rows 32j .. 32j+31 of its graph (k_compact), not 32 consecutive nodes
     const int cbase = L.node_ptr[g] + 32 * (tile - L.tile_ptr[g]);
     const int rows = min(32, L.node_ptr[g] + a.ccount[g] - cbase);
     if (rows <= 0) return;
-    if (a.count_rows && tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);
+    if (a.count_rows && tid == 0) atomicAdd(&eh_layer_rows, (unsigned long long)rows);     // measurement runs only (roofline figure)
     const int r = lane & 31, hh = lane >> 5;
     const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }
@@ -1847,7 +1348,9 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     // ---- phase 0 loads: the h tile, one 16-byte piece per thread
     f32x4 h0v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, (tid >> 4) & 31) * 64 + (tid & 15) * 4);
 
-    // targets: ranks 8k + w on even k, 8k + 7 - w on odd k (snake deal of the 32 walk lengths over the 8 waves)
+    // A wave walks 4 of the tile's rows; its time is the SUM of their degrees, so the rows are dealt to the waves
+    // longest-first in snake order (rank the 32 walk lengths, wave w takes ranks 8k + w on even k and 8k + 7 - w on
+    // odd k).  Every wave computes the same assignment from the same registers.
     const int work = (r < rows && myhs < 0) ? mydeg : 0;
     int rank = 0;
 #pragma unroll
@@ -1858,6 +1361,7 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     const int perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);   // lane p: the row of rank p & 31
     const int trow4 = __shfl(perm, 8 * (lane & 3) + ((lane & 1) ? 7 - wave : wave));   // lane k < 4: row of target k
 
+    // bit rows of this wave's 4 attention targets; requested here so the loads fly under phases 0 and A
     const int node0 = L.node_ptr[g];
     const int stride = L.adj_stride[g];
     const uint32_t* gadj = a.adj + L.adj_ptr[g];
@@ -1876,7 +1380,9 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     // ---- phase 0: h tile -> LDS
     *reinterpret_cast<f32x4*>(hp + (tid >> 4) * EH_TP + (tid & 15) * 4) = h0v;
     EH_BLOCK_SYNC();
-    const bool anynbr = __any(mydeg > 0);                                  // block-uniform (every wave holds all 32 rows)
+    // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it needs neither
+    // qt nor the attention nor the z chunks of the conv product.  Block-uniform (every wave holds all 32 rows).
+    const bool anynbr = __any(mydeg > 0);
 
     // ---- phase A: qt, column tiles wave, wave + 8
     if (anynbr && wave < 2 * HEADS) {
@@ -1898,7 +1404,12 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     }
     EH_BLOCK_SYNC();
 
-    // ---- phase B: attention of the light rows, z overwrites qt (see k_layer; four targets per wave here)
+    // ---- phase B: attention of the light rows, z overwrites qt.
+    // A wave owns 4 targets (dealt longest-first above) and walks them as ONE flat stream of neighbour visits: the
+    // decoded neighbour lists are concatenated in LDS (each padded to a whole step), so the gathers of the next step
+    // are in flight across target boundaries and the work of a wave is the SUM of its degrees, not 4 x the largest.
+    // Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS neighbours side by side (slots)
+    // and merges their softmax states when the target ends.
     if (anynbr) {
         constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;
         constexpr int UN = eh_walk_cfg<HEADS>::UN;
@@ -1906,6 +1417,8 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
         const int wgrp = lane / EH_LG, wc = lane % EH_LG;
         const int slot = wgrp / HEADS, head = wgrp % HEADS;
         uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (4 * EH_HEAVY_DEG);
+        // decode the rows into ascending lists of neighbour-row byte offsets in LDS: the first 64 words of all 4 rows
+        // together (popcount + wave prefix sums, the scans interleaved), further words row by row
         int wdeg = 0;             // lane k < 4: neighbours of target k walked here (0: isolated or heavy)
         int total_steps = 0;      // wave-uniform
         {
@@ -1960,8 +1473,10 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
             float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
 #pragma unroll
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
-            int k = -1, st = 0, nst = 0, dk = 0;
-            int krow = 0;
+            int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
+            int krow = 0;                               // tile row of target k
+            // the row offsets of a step are read from the LDS list one step before its gathers are issued
+            // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
             auto offs_of = [&](int gs, uint32_t (&o)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
@@ -1971,7 +1486,7 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
                 for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
             };
             auto compute = [&](const eh_xr (&x)[U]) {
-                if (st == nst) {
+                if (st == nst) {                         // next target with work
                     do {
                         ++k;
                         dk = __builtin_amdgcn_readlane(wdeg, k);
@@ -1987,7 +1502,7 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
                 }
                 eh_walk_step<HEADS>(q, x, dk - st * UN, slot, acc, mrun, mthr, lrun);
                 ++st;
-                if (st == nst) {
+                if (st == nst) {                         // target finished: merge the slots, write z over its qt row
                     eh_merge_slots<HEADS>(acc, mrun, lrun);
                     if (slot == 0)
                         eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
@@ -1995,6 +1510,11 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
             };
             if (total_steps > 0) {
                 if constexpr (HEADS >= 4) {
+                    // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
+                    // load instruction per four rows instead of eight per-lane gathers of the same bytes).  The tiles
+                    // live in the h tile's LDS (hp), which phase A has finished with and which is loaded again before
+                    // phase C.  Global loads run EH_WALK_DEPTH steps ahead, their offsets one more, LDS reads one;
+                    // steps past the end are skipped by predication (their clamped fetches are hits): ONE loop exit.
                     constexpr int NLD = UN / 4;
                     float* stage = hp + wave * (UN * EH_SGP);              // 8 waves x 4 rows x 68 floats = the h tile's LDS exactly
                     static_assert(8 * UN * EH_SGP <= EH_TSZ, "the staging tiles live in the h tile");
@@ -2039,6 +1559,8 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
                         }
                     }
                 } else {
+                    // HEADS <= 2: a load instruction already brings 4-8 different rows (one per slot): gather directly,
+                    // two register sets, the gathers one step ahead of their use; one loop exit (see above)
                     constexpr int EH_PF = 2;
                     eh_xr xs[EH_PF][U];
                     uint32_t on[U];
@@ -2093,55 +1615,64 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     }
     EH_BLOCK_SYNC();
 
-    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1); wave = (column tile ct, K quarter kq)
+    // ---- phase C: conv = silu(Ocat [z | h] + obias0 + [deg>0] obias1).  wave = K eighth: the 4 (HEADS + 1) operand
+    // groups of the product are dealt evenly (4 or 5 per wave with 8 heads); a wave splits each of its groups of [z | h]
+    // once and multiplies it into BOTH column tiles.  The eight partial tiles of an output are added as
+    // ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
     {
-        const int ct = wave & 1, kq = wave >> 1;
-        const int row = tid >> 4, c0 = (tid & 15) * 4;                 // epilogue: thread = (row, 4 columns)
+        const int row = tid >> 4, c0 = (tid & 15) * 4;                 // epilogues: thread = (row, 4 columns)
         const f32x4 ob0 = *reinterpret_cast<const f32x4*>(a.obias0 + (size_t)g * 64 + c0);
         const f32x4 ob1 = *reinterpret_cast<const f32x4*>(a.obias1 + (size_t)g * 64 + c0);
-        constexpr int NCH = HEADS + 1;                                  // 64-deep chunks; 4 operand groups each: NCH per quarter
-        const int G0 = kq * NCH, G1 = G0 + NCH;
-        f32x16 acc = eh_zero16();
+        constexpr int NCH = HEADS + 1, NG = 4 * NCH;
+        const int G0 = (NG * wave) / 8, G1 = (NG * (wave + 1)) / 8;    // wave-uniform
+        f32x16 acc0 = eh_zero16(), acc1 = eh_zero16();
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             if (4 * ch + 3 < G0 || 4 * ch >= G1) continue;              // wave-uniform
             if (ch < HEADS && !anynbr) continue;                        // z = 0 for the whole tile
             const float* ap = (ch < HEADS) ? qz + r * QP + ch * 64 + hh * 32 : hp + r * EH_TP + hh * 32;
-            const float* bt = a.Ocat + (size_t)(ct * NCH + ch) * EH_PK_TILE;
+            const float* bt0 = a.Ocat + (size_t)ch * EH_PK_TILE;
+            const float* bt1 = a.Ocat + (size_t)(NCH + ch) * EH_PK_TILE;
             if (4 * ch + 0 >= G0 && 4 * ch + 0 < G1)
-                eh_mma_group<0>(acc, *reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), bt, lane);
+                eh_mma_group2<0>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), bt0, bt1, lane);
             if (4 * ch + 1 >= G0 && 4 * ch + 1 < G1)
-                eh_mma_group<1>(acc, *reinterpret_cast<const f32x4*>(ap + 8), *reinterpret_cast<const f32x4*>(ap + 12), bt, lane);
+                eh_mma_group2<1>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap + 8), *reinterpret_cast<const f32x4*>(ap + 12), bt0, bt1, lane);
             if (4 * ch + 2 >= G0 && 4 * ch + 2 < G1)
-                eh_mma_group<2>(acc, *reinterpret_cast<const f32x4*>(ap + 16), *reinterpret_cast<const f32x4*>(ap + 20), bt, lane);
+                eh_mma_group2<2>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap + 16), *reinterpret_cast<const f32x4*>(ap + 20), bt0, bt1, lane);
             if (4 * ch + 3 >= G0 && 4 * ch + 3 < G1)
-                eh_mma_group<3>(acc, *reinterpret_cast<const f32x4*>(ap + 24), *reinterpret_cast<const f32x4*>(ap + 28), bt, lane);
+                eh_mma_group2<3>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap + 24), *reinterpret_cast<const f32x4*>(ap + 28), bt0, bt1, lane);
         }
+        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + row * EH_TP + c0);       // this thread's quad of h (planes below, GRU blend)
         EH_BLOCK_SYNC();                      // every wave is done reading qz
-        float* mine = pt + wave * (32 * EH_PP);
+        {
+            float* m0 = pt + (wave * 2) * 1024;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mine[eh_crow(i, lane) * EH_PP + r] = acc[i];
-        EH_BLOCK_SYNC();
-        const int ect = c0 >> 5;
-        const float* p0 = pt + ect * (32 * EH_PP) + row * EH_PP + (c0 & 31);          // quarter 0 of this column tile
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p0);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p0 + 2 * (32 * EH_PP));
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p0 + 4 * (32 * EH_PP));
-        const f32x4 v3 = *reinterpret_cast<const f32x4*>(p0 + 6 * (32 * EH_PP));
-        const bool hasnbr = dl[row] > 0;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = ((v0[e] + v1[e]) + (v2[e] + v3[e])) + ob0[e];
-            if (hasnbr) x += ob1[e];
-            v[e] = eh_silu_fast(x);
+            for (int i = 0; i < 16; ++i) {
+                m0[eh_crow(i, lane) * 32 + r] = acc0[i];
+                m0[1024 + eh_crow(i, lane) * 32 + r] = acc1[i];
+            }
         }
-        *reinterpret_cast<f32x4*>(mt + row * EH_TP + c0) = v;
-    }
-    EH_BLOCK_SYNC();
+        EH_BLOCK_SYNC();
+        f32x4 v;
+        {
+            const float* p0 = pt + (c0 >> 5) * 1024 + row * 32 + (c0 & 31);           // K eighth 0 of this column tile
+            f32x4 pv[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pv[w] = *reinterpret_cast<const f32x4*>(p0 + w * 2048);
+            const bool hasnbr = dl[row] > 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = (((pv[0][e] + pv[1][e]) + (pv[2][e] + pv[3][e])) + ((pv[4][e] + pv[5][e]) + (pv[6][e] + pv[7][e]))) + ob0[e];
+                if (hasnbr) x += ob1[e];
+                v[e] = eh_silu_fast(x);
+            }
+        }
+        EH_BLOCK_SYNC();                      // the partial tiles are dead: conv and h go there as bf16 planes
+        eh_stage3_quad(mtl, row, c0, v);
+        eh_stage3_quad(hpl, row, c0, hq);
+        EH_BLOCK_SYNC();
 
-    // ---- phase D: GRU.  wave = (gate, column tile): r = sig(Wir m + Whr h + b), z likewise, i_n = Win m + b, h_n = Whn h + b
-    {
+        // ---- phase D: GRU.  wave = (gate, column tile): r = sig(Wir m + Whr h + b), z likewise, i_n = Win m + b, h_n = Whn h + b
         const int ct = wave & 1, gate = wave >> 1;                      // 0 r, 1 z, 2 i_n, 3 h_n
         const int col = ct * 32 + r;
         float bias;
@@ -2151,16 +1682,15 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
         else bias = a.b_hh[128 + col];
         f32x16 acc = eh_zero16();
         {
-            eh_frag t0;
             eh_pfrag af, bf;
             if (gate != 3) {                                            // the conv operand: r, z, i_n
                 eh_load_frag_packed(bf, a.w_ih, 1, 2 * (gate == 2 ? 2 : gate) + ct, 0, lane);
-                eh_load_frag_lds(t0, mt, r, hh); eh_to_pfrag(af, t0);
+                eh_load_frag3_lds(af, mtl, 0, r, hh);
                 eh_mma64(acc, af, bf);
             }
             if (gate != 2) {                                            // the hidden operand: r, z, h_n (after the conv product)
                 eh_load_frag_packed(bf, a.w_hh, 1, 2 * (gate == 3 ? 2 : gate) + ct, 0, lane);
-                eh_load_frag_lds(t0, hp, r, hh); eh_to_pfrag(af, t0);
+                eh_load_frag3_lds(af, hpl, 0, r, hh);
                 eh_mma64(acc, af, bf);
             }
         }
@@ -2173,19 +1703,20 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
             for (int i = 0; i < 16; ++i) xo[i * 64 + lane] = acc[i] + bias;
         }
         EH_BLOCK_SYNC();
-        // combine: wave = (4 accumulator rows ig, column tile ct) of every lane
-        const int ig = wave >> 1;
+        // combine: thread = (row, 4 columns); in the accumulator layout row rr sits in register (rr & 3) + 4 (rr >> 3) of
+        // lanes (col & 31) + 32 ((rr >> 2) & 1): four consecutive columns are four consecutive floats
+        {
+            const float* xb = xg + (c0 >> 5) * 1024 + ((row & 3) + 4 * (row >> 3)) * 64 + (c0 & 31) + 32 * ((row >> 2) & 1);
+            const f32x4 rg = *reinterpret_cast<const f32x4*>(xb), zg = *reinterpret_cast<const f32x4*>(xb + 2048);
+            const f32x4 inn = *reinterpret_cast<const f32x4*>(xb + 4096), hn = *reinterpret_cast<const f32x4*>(xb + 6144);
+            f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * ig + j;
-            const int rr = eh_crow(i, lane);
-            const float rg = xg[(0 * 2 + ct) * 1024 + i * 64 + lane], zg = xg[(1 * 2 + ct) * 1024 + i * 64 + lane];
-            const float inn = xg[(2 * 2 + ct) * 1024 + i * 64 + lane], hn = xg[(3 * 2 + ct) * 1024 + i * 64 + lane];
-            const float ng = eh_tanh_fast(inn + rg * hn);
-            const float hv = hp[rr * EH_TP + col];
-            const float o = (1.0f - zg) * ng + zg * hv;
-            ht[rr * EH_TP + col] = o;
-            if (rr < rows) a.hnew[(size_t)nl[rr] * 64 + col] = o;
+            for (int e = 0; e < 4; ++e) {
+                const float ng = eh_tanh_fast(inn[e] + rg[e] * hn[e]);
+                o[e] = (1.0f - zg[e]) * ng + zg[e] * hq[e];
+            }
+            if (row < rows) *reinterpret_cast<f32x4*>(a.hnew + (size_t)nl[row] * 64 + c0) = o;
+            eh_stage3_quad(htl, row, c0, o);                            // over the conv planes: every product has read them
         }
     }
     EH_BLOCK_SYNC();
@@ -2193,10 +1724,7 @@ __global__ __launch_bounds__(512, 4) void k_layer8(edgehip_layout L, eh_layer_ar
     // ---- phase E: context pre-activation column sums, one 32-column tile per wave
     {
         eh_pfrag af, bf;
-        {
-            eh_frag t0;
-            eh_load_frag_lds(t0, ht, r, hh); eh_to_pfrag(af, t0);
-        }
+        eh_load_frag3_lds(af, htl, 0, r, hh);
         eh_load_frag_packed(bf, a.cw0, 1, wave, 0, lane);
         f32x16 acc = eh_zero16();
         eh_mma64(acc, af, bf);
@@ -2427,24 +1955,12 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
             case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
             default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
         }
-#ifndef EH_LAYER8
-#define EH_LAYER8 1
-#endif
-#if EH_LAYER8
         switch (h) {
-            case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<8>, dim3(NT), dim3(512), 0, s, *L, la)); break;
-            case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<4>, dim3(NT), dim3(512), 0, s, *L, la)); break;
-            case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<2>, dim3(NT), dim3(512), 0, s, *L, la)); break;
-            default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer8<1>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<2>, dim3(NT), dim3(512), 0, s, *L, la)); break;
+            default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<1>, dim3(NT), dim3(512), 0, s, *L, la)); break;
         }
-#else
-        switch (h) {
-            case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(256), 0, s, *L, la)); break;
-            case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(256), 0, s, *L, la)); break;
-            case 2: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<2>, dim3(NT), dim3(256), 0, s, *L, la)); break;
-            default: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<1>, dim3(NT), dim3(256), 0, s, *L, la)); break;
-        }
-#endif
         float* t = hcur; hcur = hnext; hnext = t;
     }
     if (h_out) {
