@@ -239,6 +239,7 @@ struct eh_ws {
     // the long ones among them (node_ptr[g+1], ..] downwards; q~ and z of a heavy row live at row `slot` of Qt / Z
     int32_t* heavy_pg;
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
+    int32_t* tperm;                    // per tile: the rows of the tile by walk length (k_layer, first layer of a pass)
     float* cwgt;
     int64_t* aptr;
     uint8_t* flags;
@@ -270,6 +271,7 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.heavy_pg = (int32_t*)take(NnP * 4);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
     w.ccount = (int32_t*)take((B + 1) * 4);
+    w.tperm = (int32_t*)take((NT + 1) * 32 * 4);
     w.act_count = (int32_t*)take((B + 1) * 4); w.kptr = (int32_t*)take((B + 2) * 4);
     w.tptr = (int32_t*)take((B + 2) * 4); w.t_graph = (int32_t*)take((B + 1) * 4);
     w.aptr = (int64_t*)take((B + 2) * 8);
@@ -1218,6 +1220,7 @@ struct eh_layer_args {
     const int32_t* idle;                               // kptr: tiles of graphs without active pairs exit (or null)
     const int32_t* crow; const float* cwgt; const int32_t* ccount;   // live rows (k_compact): node ids, weights, count per graph
     float* hnew; float* part;
+    int32_t* tperm; int perm_read;                     // [tile][32] target assignment of the step: written by the first layer, read by the others
     int count_rows;                                    // edgehip_prof_enable(1): add the processed rows to eh_layer_rows
 };
 
@@ -1300,23 +1303,45 @@ __device__ static inline void eh_mma_group2(f32x16& acc0, f32x16& acc1, const f3
     acc0 = EH_MFMA_BF16(ah, bh0, acc0); acc1 = EH_MFMA_BF16(ah, bh1, acc1);
 }
 
+// the same with A already split: `a3` points at this lane's quads of the h / m / l planes of a fragment-order tile
+template <int I>
+__device__ static inline void eh_mma_group2p(f32x16& acc0, f32x16& acc1, const unsigned* a3,
+                                             const float* __restrict__ tile0, const float* __restrict__ tile1, int lane) {
+    const eh_u32x4 ah = *reinterpret_cast<const eh_u32x4*>(a3 + I * 132);
+    const eh_u32x4 am = *reinterpret_cast<const eh_u32x4*>(a3 + EH_W3_PLANE + I * 132);
+    const eh_u32x4 al = *reinterpret_cast<const eh_u32x4*>(a3 + 2 * EH_W3_PLANE + I * 132);
+    const eh_u32x4* p0 = reinterpret_cast<const eh_u32x4*>(tile0) + lane;
+    const eh_u32x4* p1 = reinterpret_cast<const eh_u32x4*>(tile1) + lane;
+    const eh_u32x4 bh0 = p0[I * 64], bm0 = p0[256 + I * 64], bl0 = p0[512 + I * 64];
+    const eh_u32x4 bh1 = p1[I * 64], bm1 = p1[256 + I * 64], bl1 = p1[512 + I * 64];
+    acc0 = EH_MFMA_BF16(al, bh0, acc0); acc1 = EH_MFMA_BF16(al, bh1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bl0, acc0); acc1 = EH_MFMA_BF16(ah, bl1, acc1);
+    acc0 = EH_MFMA_BF16(am, bm0, acc0); acc1 = EH_MFMA_BF16(am, bm1, acc1);
+    acc0 = EH_MFMA_BF16(am, bh0, acc0); acc1 = EH_MFMA_BF16(am, bh1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bm0, acc0); acc1 = EH_MFMA_BF16(ah, bm1, acc1);
+    acc0 = EH_MFMA_BF16(ah, bh0, acc0); acc1 = EH_MFMA_BF16(ah, bh1, acc1);
+}
+
 template <int HEADS>
 __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_args a) {
     static_assert(EH_BF16X3, "the 8-wave kernel is written for the split-bf16 products");
     constexpr int H = HEADS * 64, QP = H + 4;
     constexpr int RMIN = 16 * 32 * 32;                             // the 16 partial tiles of phase C
     constexpr int R1 = (32 * QP > RMIN) ? 32 * QP : RMIN;
-    static_assert(8192 + 2 * EH_SPL <= R1, "gate exchange + conv / h' planes + h planes fit behind each other");
+    static_assert(8192 + EH_SPL <= R1, "gate exchange + conv / h' planes fit behind each other");
+    static_assert(EH_SPL <= EH_TSZ + 8 * 4 * EH_HEAVY_DEG, "the h planes fit into the staging tiles + neighbour lists");
     __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 8 * 4 * EH_HEAVY_DEG + 96];
     float* qz = lds;                    // [32][QP]       qt, then z in place                     (phases A-C)
     float* pt = lds;                    // [16][32][32]   partial tiles (K eighth, column tile)   (phase C end)
     float* xg = lds;                    // [4][2][16][64] GRU gate exchange                       (phase D)
     // operands that several waves read as MFMA fragments are split into their three bf16 planes ONCE, by the thread that
-    // produces them, and kept in fragment order (gemm.h: eh_stage3_quad / eh_load_frag3_lds): conv, h' (over conv) and h
+    // loads or produces them, and kept in fragment order (gemm.h: eh_stage3_quad / eh_load_frag3_lds): h, conv, h'
     unsigned* mtl = reinterpret_cast<unsigned*>(lds + 8192);            // conv planes                (phases C end - D)
     unsigned* htl = mtl;                                                // h' planes, over conv       (phases D end - E)
-    unsigned* hpl = reinterpret_cast<unsigned*>(lds + 8192 + EH_SPL);   // h planes                   (phase D)
-    float* hp = lds + R1;               // [32][68]       h in fp32 (phases 0, A, C, GRU blend); the walk's staging tiles in phase B
+    // h planes (phases 0 - A, and again C - D).  In phase B the same LDS holds the walk's staging tiles (hp) and the
+    // neighbour lists (idl), neither of which exists outside phase B: the planes are written again after it.
+    unsigned* hpl = reinterpret_cast<unsigned*>(lds + R1);
+    float* hp = lds + R1;               // [8 waves][4][68] staging tiles of the walk (phase B)
     int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [8 waves][4 targets][EH_HEAVY_DEG] neighbour row offsets
     int* nl = idl + 8 * 4 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
     float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
@@ -1351,14 +1376,23 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     // A wave walks 4 of the tile's rows; its time is the SUM of their degrees, so the rows are dealt to the waves
     // longest-first in snake order (rank the 32 walk lengths, wave w takes ranks 8k + w on even k and 8k + 7 - w on
     // odd k).  Every wave computes the same assignment from the same registers.
-    const int work = (r < rows && myhs < 0) ? mydeg : 0;
-    int rank = 0;
+    // The assignment depends on the step's degrees and heavy-row slots only, not on the layer: the first layer of a
+    // forward pass computes it (32 cross-lane compares per wave, a tenth of the kernel's vector instructions when every
+    // layer did it) and leaves it in the workspace, the other layers read it back.
+    int perm;                                                              // lane p: the row of rank p & 31
+    if (a.perm_read) {
+        perm = a.tperm[(size_t)tile * 32 + r];
+    } else {
+        const int work = (r < rows && myhs < 0) ? mydeg : 0;              // heavy / absent rows are not walked here
+        int rank = 0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int wj = __builtin_amdgcn_readlane(work, j);
-        rank += (wj > work || (wj == work && j < r)) ? 1 : 0;
+        for (int j = 0; j < 32; ++j) {
+            const int wj = __builtin_amdgcn_readlane(work, j);
+            rank += (wj > work || (wj == work && j < r)) ? 1 : 0;
+        }
+        perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);
+        if (tid < 32) a.tperm[(size_t)tile * 32 + tid] = perm;
     }
-    const int perm = __builtin_amdgcn_ds_permute((rank + (lane & 32)) * 4, r);   // lane p: the row of rank p & 31
     const int trow4 = __shfl(perm, 8 * (lane & 3) + ((lane & 1) ? 7 - wave : wave));   // lane k < 4: row of target k
 
     // bit rows of this wave's 4 attention targets; requested here so the loads fly under phases 0 and A
@@ -1377,8 +1411,8 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
         fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid4, k) - node0) * stride + lane] : 0u;
     }
 
-    // ---- phase 0: h tile -> LDS
-    *reinterpret_cast<f32x4*>(hp + (tid >> 4) * EH_TP + (tid & 15) * 4) = h0v;
+    // ---- phase 0: h tile -> LDS, as bf16 planes
+    eh_stage3_quad(hpl, tid >> 4, (tid & 15) * 4, h0v);
     EH_BLOCK_SYNC();
     // A tile whose rows are all isolated (class representatives, k_compact puts them last) has z = 0: it needs neither
     // qt nor the attention nor the z chunks of the conv product.  Block-uniform (every wave holds all 32 rows).
@@ -1386,10 +1420,8 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
 
     // ---- phase A: qt, column tiles wave, wave + 8
     if (anynbr && wave < 2 * HEADS) {
-        eh_frag af0;
         eh_pfrag af;
-        eh_load_frag_lds(af0, hp, r, hh);
-        eh_to_pfrag(af, af0);
+        eh_load_frag3_lds(af, hpl, 0, r, hh);
 #pragma unroll
         for (int nt = wave; nt < 2 * HEADS; nt += 8) {
             eh_pfrag bf;
@@ -1607,11 +1639,11 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
             }
         }
     }
-    if (HEADS >= 4 && anynbr) {
-        // the walk used the h tile's LDS as its staging tiles: bring the tile back
+    if (anynbr) {
+        // the walk's staging tiles and neighbour lists lay over the h planes: bring them back
         h0v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, (tid >> 4) & 31) * 64 + (tid & 15) * 4);
-        EH_BLOCK_SYNC();                      // every wave is done with its staging tile
-        *reinterpret_cast<f32x4*>(hp + (tid >> 4) * EH_TP + (tid & 15) * 4) = h0v;
+        EH_BLOCK_SYNC();                      // every wave is done with its staging tile and its lists
+        eh_stage3_quad(hpl, tid >> 4, (tid & 15) * 4, h0v);
     }
     EH_BLOCK_SYNC();
 
@@ -1630,9 +1662,17 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
         for (int ch = 0; ch < NCH; ++ch) {
             if (4 * ch + 3 < G0 || 4 * ch >= G1) continue;              // wave-uniform
             if (ch < HEADS && !anynbr) continue;                        // z = 0 for the whole tile
-            const float* ap = (ch < HEADS) ? qz + r * QP + ch * 64 + hh * 32 : hp + r * EH_TP + hh * 32;
             const float* bt0 = a.Ocat + (size_t)ch * EH_PK_TILE;
             const float* bt1 = a.Ocat + (size_t)(NCH + ch) * EH_PK_TILE;
+            if (ch == HEADS) {                                          // the h chunk: already split
+                const unsigned* hq3 = hpl + hh * 528 + r * 4;
+                if (4 * ch + 0 >= G0 && 4 * ch + 0 < G1) eh_mma_group2p<0>(acc0, acc1, hq3, bt0, bt1, lane);
+                if (4 * ch + 1 >= G0 && 4 * ch + 1 < G1) eh_mma_group2p<1>(acc0, acc1, hq3, bt0, bt1, lane);
+                if (4 * ch + 2 >= G0 && 4 * ch + 2 < G1) eh_mma_group2p<2>(acc0, acc1, hq3, bt0, bt1, lane);
+                if (4 * ch + 3 >= G0 && 4 * ch + 3 < G1) eh_mma_group2p<3>(acc0, acc1, hq3, bt0, bt1, lane);
+                continue;
+            }
+            const float* ap = qz + r * QP + ch * 64 + hh * 32;
             if (4 * ch + 0 >= G0 && 4 * ch + 0 < G1)
                 eh_mma_group2<0>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), bt0, bt1, lane);
             if (4 * ch + 1 >= G0 && 4 * ch + 1 < G1)
@@ -1642,7 +1682,7 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
             if (4 * ch + 3 >= G0 && 4 * ch + 3 < G1)
                 eh_mma_group2<3>(acc0, acc1, *reinterpret_cast<const f32x4*>(ap + 24), *reinterpret_cast<const f32x4*>(ap + 28), bt0, bt1, lane);
         }
-        const f32x4 hq = *reinterpret_cast<const f32x4*>(hp + row * EH_TP + c0);       // this thread's quad of h (planes below, GRU blend)
+        const f32x4 hq = h0v;                 // this thread's quad of h in fp32 (row, c0): the GRU blend needs it
         EH_BLOCK_SYNC();                      // every wave is done reading qz
         {
             float* m0 = pt + (wave * 2) * 1024;
@@ -1667,9 +1707,8 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
                 v[e] = eh_silu_fast(x);
             }
         }
-        EH_BLOCK_SYNC();                      // the partial tiles are dead: conv and h go there as bf16 planes
+        EH_BLOCK_SYNC();                      // the partial tiles are dead: conv goes there as bf16 planes
         eh_stage3_quad(mtl, row, c0, v);
-        eh_stage3_quad(hpl, row, c0, hq);
         EH_BLOCK_SYNC();
 
         // ---- phase D: GRU.  wave = (gate, column tile): r = sig(Wir m + Whr h + b), z likewise, i_n = Win m + b, h_n = Whn h + b
@@ -1926,6 +1965,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
         la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
         la.crow = w.crow; la.cwgt = w.cwgt; la.ccount = w.ccount;
+        la.tperm = w.tperm; la.perm_read = l > 0 ? 1 : 0;
         la.count_rows = eh_prof_on() ? 1 : 0;
         // per-graph update of this layer and qt of the heavy rows (gathered-row GEMM into the compact buffer
         // w.Qt) in ONE launch: they are independent, and each alone is a latency-bound launch
