@@ -33,7 +33,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md, BF16 dense
 BF16_PRODUCTS_PER_FP32 = 6        # csrc/gemm.h: exact 3-way bf16 split of both operands, six products kept
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md, HBM3E peak
 SURVEY_GB_PER_GRAPH = 40.7        # bytes of the UNFOLDED formulation per sampled polblogs graph
-PMC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')     # newest first
+PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')     # newest first
 
 
 def parse_args():

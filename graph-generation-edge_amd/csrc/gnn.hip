@@ -590,17 +590,19 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
     if (tid < width) {
         // eight independent partial sums: the tile loads of a trip are all in flight together (a plain
         // `s += part[..]` loop waits for every load in turn: ~40 L2 round trips per launch)
-        // 24 tiles per trip (a trip costs one L2 round trip; 39 tiles of a polblogs graph: two trips); the sums keep
-        // the order of 8-tile trips: tile t0 + 8k + j goes to ps[j], k ascending (masked tiles add 0)
+        // 40 tiles per trip (a trip costs one round trip to memory - the sums were written by another kernel, possibly
+        // through another XCD's L2; the 39 tiles of a polblogs graph: ONE trip, it was two with 24); the sums keep the
+        // order of 8-tile trips: tile t0 + 8k + j goes to ps[j], k ascending (masked tiles add 0)
+        constexpr int TRIP = 40;
         float ps[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) ps[j] = 0.f;
-        for (int t = t0; t < t1; t += 24) {
-            float x[24];
+        for (int t = t0; t < t1; t += TRIP) {
+            float x[TRIP];
 #pragma unroll
-            for (int j = 0; j < 24; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
+            for (int j = 0; j < TRIP; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < TRIP / 8; ++k)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ps[j] += x[8 * k + j];
         }
