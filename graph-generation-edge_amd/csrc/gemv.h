@@ -16,7 +16,8 @@ __device__ static inline float eh_dpp_f(float v, const int ctrl_sel) {
 // Block-cooperative GEMV for the per-graph vectors: y[o] = bias[o] + W1[o,:K1] . x1 (+ W2[o,:64] . x2).
 // 16 lanes per output row, one float4 per lane and 64-wide chunk: every wave-level load covers four
 // complete 256-byte rows (thread-per-row reads touched 64 cache lines per instruction and made this
-// latency-bound kernel 3x slower).  x vectors live in LDS.  Outputs o = first + 16*pass + 4*wave + sub.
+// latency-bound kernel 3x slower).  x vectors live in LDS.  Outputs o = first + 4*NW*pass + 4*wave + sub for a block of
+// NW waves (the arithmetic of an output does not depend on NW).
 __device__ static inline float eh_row16_sum(float v) {
     v += eh_dpp_f(v, 0);                                                                    // xor 1
     v += eh_dpp_f(v, 1);                                                                    // xor 2
@@ -24,7 +25,7 @@ __device__ static inline float eh_row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row mirror (16)
     return v;
 }
-template <int K1, bool TWO>
+template <int K1, bool TWO, int NW = 4>
 __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld1, const float* __restrict__ x1,
                                             const float* __restrict__ W2, int ld2, const float* __restrict__ x2,
                                             const float* __restrict__ bias, int first, int count, float* __restrict__ y,
@@ -38,11 +39,11 @@ __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld
     // PB passes (16 outputs each) per trip, all their loads (16 float4 per lane) issued before the first
     // reduction: a trip costs one L2 round trip
     constexpr int PB = 16 / (K1 / 64 + (TWO ? 1 : 0));
-    for (int o0 = first + 4 * wave + sub; o0 < first + count; o0 += 16 * PB) {
+    for (int o0 = first + 4 * wave + sub; o0 < first + count; o0 += 4 * NW * PB) {
         f32x4 w1[PB][K1 / 64], w2[PB];
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int o = o0 + 16 * p;
+            const int o = o0 + 4 * NW * p;
             const int oc = o < first + count ? o : o0;            // clamp: a valid row, result discarded
 #pragma unroll
             for (int j = 0; j < K1 / 64; ++j)
@@ -51,7 +52,7 @@ __device__ static inline void eh_block_gemv(const float* __restrict__ W1, int ld
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int o = o0 + 16 * p;
+            const int o = o0 + 4 * NW * p;
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < K1 / 64; ++j)

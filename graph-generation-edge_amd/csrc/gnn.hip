@@ -220,24 +220,10 @@ extern "C" int edgehip_gnn_prepare(const edgehip_gnn_params* P, float* folded, v
 // --------------------------------------------------------------------------------------------
 // workspace carving
 // --------------------------------------------------------------------------------------------
-// Heavy-row counters of a step, one zero-filled int32 block: [g] heavy rows of graph g that are not long,
-// [EH_HC_LONG(B) + g] its long rows.  Per graph, not per launch: a counter that every tile of the launch adds to is
-// one address at the memory side, ~15 ns per add (2 496 tiles: 37 us of k_step_prepare's 41).
-#define EH_HC_LONG(B) ((B) + 16)
-#define EH_HC_INTS(B) (2 * ((size_t)(B) + 16))
-// Heavy rows are walked on the XCD that owns their graph: graphs are dealt to the 8 XCDs in contiguous ranges, the
-// same ranges the fused layer kernel's tile order gives them, so a graph's h rows (313 KB for polblogs) are gathered
-// through ONE L2 instead of all eight.
-__host__ __device__ static inline int eh_xcd_of_graph(int g, int B) { return (int)((long long)g * 8 / B); }
-__host__ __device__ static inline int eh_xcd_first_graph(int x, int B) { return (int)(((long long)x * B + 7) / 8); }
-
 struct eh_ws {
-    float *hA, *hB, *Qt, *Z, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
+    float *hA, *hB, *part, *ctx, *qbias, *obias0, *obias1, *cbias;
     // step-level scratch
-    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph, *heavy_slot, *heavy_count;
-    // per-graph heavy lists inside the graph's own node range: slot -> node.  Heavy rows fill [node_ptr[g], ..) upwards,
-    // the long ones among them (node_ptr[g+1], ..] downwards; q~ and z of a heavy row live at row `slot` of Qt / Z
-    int32_t* heavy_pg;
+    int32_t *deg, *act_nodes, *act_count, *kptr, *tptr, *t_graph;
     int32_t *crow, *rep_of, *ccount;   // live rows of every graph (k_compact)
     int32_t* tperm;                    // per tile: the rows of the tile by walk length (k_layer, first layer of a pass)
     float* cwgt;
@@ -258,7 +244,6 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     size_t H = (size_t)hmax * EH_D;
     size_t NnP = Nn + 32;   // slack row block so clamped fragment loads stay inside
     w.hA = (float*)take(NnP * 64 * 4); w.hB = (float*)take(NnP * 64 * 4);
-    w.Qt = (float*)take(NnP * H * 4); w.Z = (float*)take(NnP * H * 4);
     w.part = (float*)take((NT + 1) * 256 * 4);
     w.ctx = (float*)take((size_t)2 * (B + 1) * 64 * 4);    // two copies: layer l reads one, writes the other
     w.qbias = (float*)take((B + 1) * H * 4);
@@ -266,9 +251,6 @@ static eh_ws eh_carve(const edgehip_layout* L, const edgehip_gnn_params* P, void
     w.cbias = (float*)take((B + 1) * 256 * 4);
     w.deg = (int32_t*)take(NnP * 4);
     w.act_nodes = (int32_t*)take(NnP * 4);
-    w.heavy_slot = (int32_t*)take(NnP * 4);
-    w.heavy_count = (int32_t*)take(EH_HC_INTS(B) * 4);
-    w.heavy_pg = (int32_t*)take(NnP * 4);
     w.crow = (int32_t*)take(NnP * 4); w.rep_of = (int32_t*)take(NnP * 4); w.cwgt = (float*)take(NnP * 4);
     w.ccount = (int32_t*)take((B + 1) * 4);
     w.tperm = (int32_t*)take((NT + 1) * 32 * 4);
@@ -474,22 +456,21 @@ __device__ static inline bool eh_graph_idle(const int32_t* __restrict__ kptr, in
     return kptr != nullptr && kptr[g + 1] - kptr[g] < 2;
 }
 
-// rows with more neighbours than this are walked by k_attn_heavy instead of the fused layer kernel
+// rows with more neighbours than EH_LONG_DEG are walked by all eight waves of their tile together (k_layer, phase B);
+// EH_HEAVY_DEG only classifies rows in the step statistics (edgehip_prof_step_stats)
 #ifndef EH_HEAVY_DEG
-#define EH_HEAVY_DEG 48         // multiple of every eh_walk_cfg<h>::UN (lists are padded to whole steps)
+#define EH_HEAVY_DEG 48
 #endif
 #ifndef EH_LONG_DEG
-#define EH_LONG_DEG 128         // heavy rows with more neighbours go first in k_attn_heavy
+#define EH_LONG_DEG 192
 #endif
 
-// One launch for the three per-step preparations that only need (deg, d0, flags, kptr): blocks
-// [0, tile_blocks) compute h0 and list the heavy rows of their tiles, the last B blocks build the live-row
-// lists (k_compact body).
+// One launch for the per-step preparations that only need (deg, d0, flags, kptr): blocks [0, tile_blocks) compute h0
+// and its column sums, the last B blocks build the live-row lists (k_compact body).
 struct eh_prep_args {
     int max_degree; const float *at, *a0, *as;
     const int32_t *deg, *d0; const uint8_t* flags; const int32_t* idle;
     float *h0, *part;
-    int32_t *heavy_count, *heavy_slot, *heavy_pg;
     int dedupe; int32_t* crow; float* cwgt; int32_t *rep_of, *ccount;
     int tile_blocks;
 };
@@ -507,20 +488,6 @@ __global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_
     if (tile >= L.num_tiles) return;
     if (eh_graph_idle(p.idle, L.tile_graph[tile])) return;
     int row0 = L.tile_row0[tile], rows = L.tile_rows[tile];
-    // heavy rows get a slot in their graph's list (any order: slots are independent): one atomic instruction per
-    // wave (lane 0: the graph's heavy rows that are not long, lane 1: its long rows).  The long rows are listed apart
-    // because k_attn_heavy starts them first (they set its tail).  The result is first used after the h0 rows below.
-    const int hi = row0 + lane;
-    const int hd = lane < rows ? deg[hi] : 0;
-    const bool lg = hd > EH_LONG_DEG, hv = hd > EH_HEAVY_DEG && !lg;
-    const unsigned long long mh = __ballot(hv), ml = __ballot(lg);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int hg = L.tile_graph[tile];
-    int mine = 0;
-    if (lane < 2) {
-        const int add = lane ? __popcll(ml) : __popcll(mh);
-        if (add) mine = atomicAdd(p.heavy_count + (lane ? EH_HC_LONG(L.num_graphs) : 0) + hg, add);
-    }
     float vat = at[lane], va0 = a0[lane], vs0 = as[lane], vs1 = as[64 + lane];
     float md = (float)max_degree;
     float sum = 0.f;
@@ -539,14 +506,6 @@ __global__ __launch_bounds__(256) void k_step_prepare(edgehip_layout L, eh_prep_
         float v = eh_silu(vat * xt + va0 * x0 + (fl ? vs1 : vs0));
         h0[(size_t)i * 64 + lane] = v;
         sum += v;
-    }
-    {
-        const int baseh = __shfl(mine, 0), basel = __shfl(mine, 1);
-        int slot = -1;
-        if (hv) slot = L.node_ptr[hg] + baseh + __popcll(mh & below);
-        if (lg) slot = L.node_ptr[hg + 1] - 1 - (basel + __popcll(ml & below));
-        if (slot >= 0) p.heavy_pg[slot] = hi;
-        if (lane < rows) p.heavy_slot[hi] = slot;
     }
     part[(size_t)tile * 256 + lane] = sum;
 }
@@ -574,13 +533,18 @@ struct eh_update_args {
     const int32_t* idle; const int32_t* ccount;
 };
 
-__device__ static inline void eh_graph_update_body(const edgehip_layout& L, const edgehip_gnn_params& P, int l, const eh_layer_ptrs& lp,
+// NW waves per block.  TAIL = false: one of EH_GU_PARTS blocks of a graph (k_graph_update).  TAIL = true: the last tile
+// of graph g to finish inside k_layer runs the whole update (every part's share), `part` having been written by other
+// blocks of the SAME launch - it is read with agent-scope loads.  `sm`: 768 floats of LDS.  Outputs are bit-identical
+// between the two forms (the same sums in the same order).
+template <int NW, bool TAIL>
+__device__ static inline void eh_graph_update_body(float* __restrict__ sm, const edgehip_layout& L, const edgehip_gnn_params& P, int l, const eh_layer_ptrs& lp,
                                                       const float* __restrict__ part, const float* __restrict__ te /*[T][L][64]*/,
                                                       const int32_t* __restrict__ t_graph, int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
                                                       int ldq, float* __restrict__ obias0, float* __restrict__ obias1,
                                                       float* __restrict__ cbias, const int32_t* __restrict__ idle,
                                                       const int32_t* __restrict__ ccount, int g, int prt) {
-    __shared__ __attribute__((aligned(16))) float mean[256], v[64], hid[256], cn[64], tev[64], zero64[64];
+    float *mean = sm, *hid = sm + 256, *v = sm + 512, *cn = sm + 576, *tev = sm + 640, *zero64 = sm + 704;
     const int tid = threadIdx.x;
     if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
@@ -600,7 +564,10 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
         for (int t = t0; t < t1; t += TRIP) {
             float x[TRIP];
 #pragma unroll
-            for (int j = 0; j < TRIP; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
+            for (int j = 0; j < TRIP; ++j) {
+                if (TAIL) x[j] = (t + j < t1) ? __hip_atomic_load(part + (size_t)(t + j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                else x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < TRIP / 8; ++k)
 #pragma unroll
@@ -618,152 +585,80 @@ __device__ static inline void eh_graph_update_body(const edgehip_layout& L, cons
         if (tid < 64) v[tid] = mean[tid];
     } else {
         const float cold = tid < 64 ? ctx_in[(size_t)g * 64 + tid] : 0.f;      // in flight under the GEMV
-        eh_block_gemv<256, false>(P.context_w2, 256, mean, nullptr, 0, nullptr, P.context_b2, 0, 64, v, 0);
+        eh_block_gemv<256, false, NW>(P.context_w2, 256, mean, nullptr, 0, nullptr, P.context_b2, 0, 64, v, 0);
         __syncthreads();
         if (tid < 64) v[tid] += cold;
     }
     __syncthreads();
-    eh_block_gemv<64, false>(P.global_w0, 64, v, nullptr, 0, nullptr, P.global_b0, 0, 256, hid, 1);
+    eh_block_gemv<64, false, NW>(P.global_w0, 64, v, nullptr, 0, nullptr, P.global_b0, 0, 256, hid, 1);
     __syncthreads();
-    eh_block_gemv<256, false>(P.global_w2, 256, hid, nullptr, 0, nullptr, P.global_b2, 0, 64, cn, 0);
+    eh_block_gemv<256, false, NW>(P.global_w2, 256, hid, nullptr, 0, nullptr, P.global_b2, 0, 64, cn, 0);
     __syncthreads();
     // the parts of a graph are independent blocks: the old context is read from ctx_in and the new one goes
     // to the other copy (ctx), so a late part never sees a half-updated value
     if (l >= P.num_layers) {
-        if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+        if ((TAIL || prt == 0) && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
         return;
     }
     const float* xc = (l > 0) ? cn : zero64;      // layer 0 sees x = h0 (no context added yet)
     {   // qbias[o] = mbcat[o] + Mtcat[o,:] . te + Mcat[o,:] . ctx      share of this part
         const int per = ((lp.H / 16 + EH_GU_PARTS - 1) / EH_GU_PARTS) * 16;
-        const int first = prt * per;
-        const int count = first + per <= lp.H ? per : (lp.H > first ? lp.H - first : 0);
-        eh_block_gemv<64, true>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
+        const int first = TAIL ? 0 : prt * per;
+        const int count = TAIL ? lp.H : (first + per <= lp.H ? per : (lp.H > first ? lp.H - first : 0));
+        eh_block_gemv<64, true, NW>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
     }
     // cbias = context_b0 + context_w0[:, 64:128] . ctx (64 rows per part) and, on parts 1 and 2,
     // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx  /  obias1 = bvbar + Vbbar . te + Vsum . ctx:
     // 64 outputs each, their weight rows requested together (one L2 round trip instead of two; same arithmetic)
     {
         static_assert(256 / EH_GU_PARTS == 64, "four passes of 16 outputs per job");
-        const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, kq = lane & 15;
-        const bool two = prt == 1 || prt == 2;                         // block-uniform
-        const float* Wt = prt == 1 ? lp.skip_w + 64 : lp.Vbbar;        // . te
-        const float* Wx = prt == 1 ? lp.skip_w : lp.Vsum;              // . ctx (layer 0: zeros)
-        const int ldo = prt == 1 ? 128 : 64;
-        const float* ob = prt == 1 ? lp.skip_b : lp.bvbar;
-        float* oy = (prt == 1 ? obias0 : obias1) + (size_t)g * 64;
+        static_assert(!TAIL || NW == 8, "the tail form deals the four parts to two groups of four waves");
+        const int lane = tid & 63, wave = (tid >> 6) & 3, sub = lane >> 4, kq = lane & 15;
         const f32x4 xcn = *reinterpret_cast<const f32x4*>(cn + 4 * kq);
         const f32x4 xte = *reinterpret_cast<const f32x4*>(tev + 4 * kq);
         const f32x4 xx = *reinterpret_cast<const f32x4*>(xc + 4 * kq);
-        f32x4 wc[4], wt[4], wx[4];
+        // TAIL: waves 0-3 take parts 0 and 2, waves 4-7 parts 1 and 3
+        for (int pr = TAIL ? (tid >> 8) : prt; pr < (TAIL ? EH_GU_PARTS : prt + 1); pr += TAIL ? 2 : 1) {
+            const bool two = pr == 1 || pr == 2;                          // wave-uniform
+            const float* Wt = pr == 1 ? lp.skip_w + 64 : lp.Vbbar;        // . te
+            const float* Wx = pr == 1 ? lp.skip_w : lp.Vsum;              // . ctx (layer 0: zeros)
+            const int ldo = pr == 1 ? 128 : 64;
+            const float* ob = pr == 1 ? lp.skip_b : lp.bvbar;
+            float* oy = (pr == 1 ? obias0 : obias1) + (size_t)g * 64;
+            f32x4 wc[4], wt[4], wx[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int o = 16 * p + 4 * wave + sub;
-            wc[p] = *reinterpret_cast<const f32x4*>(P.context_w0 + 64 + (size_t)(prt * 64 + o) * 128 + 4 * kq);
-            if (two) {
-                wt[p] = *reinterpret_cast<const f32x4*>(Wt + (size_t)o * ldo + 4 * kq);
-                wx[p] = *reinterpret_cast<const f32x4*>(Wx + (size_t)o * ldo + 4 * kq);
+            for (int p = 0; p < 4; ++p) {
+                const int o = 16 * p + 4 * wave + sub;
+                wc[p] = *reinterpret_cast<const f32x4*>(P.context_w0 + 64 + (size_t)(pr * 64 + o) * 128 + 4 * kq);
+                if (two) {
+                    wt[p] = *reinterpret_cast<const f32x4*>(Wt + (size_t)o * ldo + 4 * kq);
+                    wx[p] = *reinterpret_cast<const f32x4*>(Wx + (size_t)o * ldo + 4 * kq);
+                }
             }
-        }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int o = 16 * p + 4 * wave + sub;
-            float sc = 0.f;
-            sc += wc[p][0] * xcn[0] + wc[p][1] * xcn[1] + wc[p][2] * xcn[2] + wc[p][3] * xcn[3];
-            sc = eh_row16_sum(sc);
-            if (kq == 0) cbias[(size_t)g * 256 + prt * 64 + o] = sc + P.context_b0[prt * 64 + o];
-            if (two) {
-                float so = 0.f;
-                so += wt[p][0] * xte[0] + wt[p][1] * xte[1] + wt[p][2] * xte[2] + wt[p][3] * xte[3];
-                so += wx[p][0] * xx[0] + wx[p][1] * xx[1] + wx[p][2] * xx[2] + wx[p][3] * xx[3];
-                so = eh_row16_sum(so);
-                if (kq == 0) oy[o] = so + ob[o];
+            for (int p = 0; p < 4; ++p) {
+                const int o = 16 * p + 4 * wave + sub;
+                float sc = 0.f;
+                sc += wc[p][0] * xcn[0] + wc[p][1] * xcn[1] + wc[p][2] * xcn[2] + wc[p][3] * xcn[3];
+                sc = eh_row16_sum(sc);
+                if (kq == 0) cbias[(size_t)g * 256 + pr * 64 + o] = sc + P.context_b0[pr * 64 + o];
+                if (two) {
+                    float so = 0.f;
+                    so += wt[p][0] * xte[0] + wt[p][1] * xte[1] + wt[p][2] * xte[2] + wt[p][3] * xte[3];
+                    so += wx[p][0] * xx[0] + wx[p][1] * xx[1] + wx[p][2] * xx[2] + wx[p][3] * xx[3];
+                    so = eh_row16_sum(so);
+                    if (kq == 0) oy[o] = so + ob[o];
+                }
             }
         }
     }
-    if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+    if ((TAIL || prt == 0) && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
 }
 
 __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, eh_update_args u) {
-    eh_graph_update_body(L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
+    __shared__ __attribute__((aligned(16))) float sm[768];
+    eh_graph_update_body<4, false>(sm, L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
                          u.obias1, u.cbias, u.idle, u.ccount, blockIdx.x / EH_GU_PARTS, blockIdx.x % EH_GU_PARTS);
-}
-
-// q~ of the heavy rows: Y[slot] = Mcat h[heavy_pg[slot]] over the graphs' slot lists.  The rows are enumerated as ONE
-// compact sequence (graph 0's heavy rows, its long rows, graph 1's ..) so that the 32-row tiles are full; a wave finds
-// the (graph, position) of its 32 rows from the per-graph counts with a wave prefix sum (no index array, no counter
-// that every tile of a launch would have to add to).
-struct eh_hq_args {
-    const float* A; const float* W; float* Y; int H;         // h rows [*,64], packed Mcat, q~ [slot][H]
-    const int32_t *seg_ptr, *seg_lo, *seg_hi, *row_of; int nseg;
-};
-__device__ static inline void eh_heavy_qt_body(const eh_hq_args& d, int ng_per_block, int bx, int by) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int m0 = (bx * 4 + wave) * 32;
-    int run = 0, myg = 0, myk = 0;
-    for (int base = 0; base < d.nseg; base += 64) {
-        const int gi = base + lane;
-        int incl = gi < d.nseg ? d.seg_lo[gi] + d.seg_hi[gi] : 0;
-        incl = eh_wave_scan_incl(incl);
-        const int tot = __builtin_amdgcn_readlane(incl, 63);
-        if (run + tot > m0 && run < m0 + 32) {
-            for (int rr = 0; rr < 32; ++rr) {
-                const int mr = m0 + rr - run;                           // wave-uniform
-                if (mr < 0 || mr >= tot) continue;
-                const int q = __popcll(__ballot(incl <= mr));          // graphs of this chunk that end at or before mr
-                const int before = q ? __builtin_amdgcn_readlane(incl, q - 1) : 0;
-                if ((lane & 31) == rr) { myg = base + q; myk = mr - before; }
-            }
-        }
-        run += tot;
-    }
-    if (m0 >= run) return;
-    const int rows = run - m0 < 32 ? run - m0 : 32;
-    const int r = lane & 31, hh = lane >> 5;
-    {   // rows past the end repeat the last one (computed, not stored)
-        const int src = (r < rows ? r : rows - 1) + (lane & 32);
-        myg = __shfl(myg, src); myk = __shfl(myk, src);
-    }
-    const int lo = d.seg_lo[myg];
-    const int slot = myk < lo ? d.seg_ptr[myg] + myk : d.seg_ptr[myg + 1] - 1 - (myk - lo);
-    const float* ap = d.A + (size_t)d.row_of[slot] * 64 + hh * 32;
-    eh_frag a;
-    eh_pfrag a3;
-    eh_load_frag(a, ap);
-    eh_to_pfrag(a3, a);
-    int yrow[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) yrow[i] = __shfl(slot, eh_crow(i, lane));
-    const int ng_total = d.H / 32;
-    const int ng0 = by * ng_per_block;
-    const int ng1 = (ng0 + ng_per_block < ng_total) ? ng0 + ng_per_block : ng_total;
-    for (int ng = ng0; ng < ng1; ++ng) {
-        f32x16 acc = eh_zero16();
-        eh_pfrag b;
-        eh_load_frag_packed(b, d.W, 1, ng, 0, lane);
-        eh_mma64(acc, a3, b);
-        const int col = ng * 32 + r;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (eh_crow(i, lane) < rows) d.Y[(size_t)yrow[i] * d.H + col] = acc[i];
-    }
-}
-
-// One launch, two independent jobs side by side (block specialisation): the per-graph update of layer l
-// (blocks [0, nb_update)) and the gathered-row qt GEMM of the heavy rows (the rest).  Neither reads what the
-// other writes; run back to back they were two latency-bound launches on the critical path of every layer.
-__global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, edgehip_gnn_params P, eh_update_args u,
-                                                            int nb_update, eh_hq_args d, int gx, int per) {
-    const int b = blockIdx.x;
-    if (b < nb_update) {
-        eh_graph_update_body(L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
-                             u.obias1, u.cbias, u.idle, u.ccount, b / EH_GU_PARTS, b % EH_GU_PARTS);
-    } else {
-        const int bb = b - nb_update;
-        // one accumulator per wave: 151 instead of 204 registers for the whole kernel, 3 waves per SIMD
-        // (single stream 122.5 -> 124.4 graphs/s)
-        eh_heavy_qt_body(d, per, bb % gx, bb / gx);
-    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -773,10 +668,10 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
 // the 8 groups are the 8 heads of ONE neighbour; HEADS < 8: 8/HEADS neighbours side by side (slots) whose
 // states are merged when the target ends.
 //
-// Degrees are skewed (polblogs: mean 27, max ~350).  Rows with at most EH_HEAVY_DEG neighbours are walked
-// inside the fused layer kernel (phase B: a wave's 8 targets as one flat stream).  Heavier rows are listed
-// once per step (k_step_prepare) and, per layer, get one WAVE each (k_attn_heavy), their qt coming from a
-// gathered-row GEMM; z goes to zheavy[slot] and the fused kernel copies it instead of walking the row.
+// Degrees are skewed (polblogs: mean 27, max ~350).  Every row is walked inside the fused layer kernel (phase B): a
+// wave's targets as one flat stream of visits passing through its list in windows, rows with more than EH_LONG_DEG
+// neighbours by all eight waves of the tile together.  (Rounds 1-3 gave rows above 48 neighbours a kernel of their
+// own, one wave per row, fed by a gathered-row qt product: two more dependent launches per layer.)
 // --------------------------------------------------------------------------------------------
 #define EH_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -787,7 +682,7 @@ __global__ __launch_bounds__(256) void k_update_and_heavy_qt(edgehip_layout L, e
 // group and EH_CPL/HEADS neighbours run side by side (slots; merged with eh_merge_slots when the target
 // ends).  EH_CPL = 8 is the measured optimum on polblogs: 16 halves the per-visit reduction / softmax
 // overhead on paper but lengthens the dependent FMA chains, doubles the slot merges and costs occupancy
-// (k_attn_heavy 98 -> 154 VGPRs): 14-25 % slower end to end.
+// (98 -> 154 VGPRs in a walk-only kernel): 14-25 % slower end to end.
 // U rounds per step: scores of the step first, one rescale, then the weighted sum; the rows of the next
 // step are in flight while the current one is consumed (two register sets).
 #ifndef EH_CPL
@@ -1003,7 +898,7 @@ __device__ static inline void eh_walk_list(const uint32_t* __restrict__ list, in
 // The same walk with the neighbour rows passed through LDS.  In eh_walk_list every lane gathers its own 32 bytes of
 // a neighbour row, and the HEADS groups of a slot gather the SAME bytes: a row of 256 B costs the address unit (TA,
 // 64 B per clock and CU) 2 KB worth of lanes, 32 cycles per visit against ~76 vector-ALU cycles per visit per SIMD -
-// with all four SIMDs walking the TA is the bound (PMC: TA busy 85 % of k_attn_heavy, 59 % of k_layer).  Here ONE
+// with all four SIMDs walking the TA is the bound (PMC, round 2: TA busy 85 % of a walk-only kernel, 59 % of k_layer).  Here ONE
 // load instruction brings four whole rows (lane = 16-byte piece), the rows go to a wave-private LDS tile and the
 // lanes read their channels from there (identical addresses broadcast): 4 TA cycles per visit.  LDS operations of a
 // wave execute in order, so the tile needs no second buffer: the reads of step s are issued before the write of
@@ -1111,97 +1006,6 @@ __device__ static inline void eh_merge_slots(f32x2 (&acc)[EH_CPL / 2], float& m,
     if constexpr (O0 <= 32) eh_merge_stage<32>(acc, lsum);
 }
 
-// Heavy rows: ONE WAVE per row, and one wave per BLOCK: the rows differ widely in length (49 .. 350
-// neighbours on polblogs), and a 4-wave block keeps its CU slots until its longest row is done (measured: 5.9
-// of 12 resident waves per CU on average).  Single-wave blocks are replaced as they finish.  Per 64-word
-// chunk of the bit row the wave decodes the neighbour ids into its LDS list (popcount + prefix sum) and
-// walks them with eh_walk_list.
-template <int HEADS>
-__global__ __launch_bounds__(64) void k_attn_heavy(edgehip_layout L, const uint32_t* __restrict__ adj,
-                                                    const float* __restrict__ hsrc, const float* __restrict__ qheavy /*[slot,H]*/,
-                                                    const float* __restrict__ qbias, int ldq,
-                                                    const int32_t* __restrict__ counter, const int32_t* __restrict__ heavy_pg,
-                                                    float* __restrict__ zheavy) {
-    constexpr int H = HEADS * 64;
-    constexpr int UN = eh_walk_cfg<HEADS>::UN;
-#ifndef EH_HCHUNK
-#define EH_HCHUNK 64                   // bit-row words decoded per chunk (<= 64: one word per lane)
-#endif
-    __shared__ uint32_t list[32 * EH_HCHUNK + 16];  // a chunk holds at most 32 * EH_HCHUNK neighbours (+ step padding)
-    __shared__ __attribute__((aligned(16))) float stage[UN * EH_SGP];      // rows of the step in flight (eh_walk_list_staged)
-    const int lane = threadIdx.x;
-    const int grp = lane / EH_LG, c = lane % EH_LG;
-    const int slot = grp / HEADS, head = grp % HEADS;
-    // XCD ownership: blocks b, b+8, .. share an XCD (round-robin dispatch); XCD x walks the heavy rows of ITS graphs
-    // (eh_xcd_of_graph: contiguous ranges of B/8 graphs, the ranges k_layer's tile order gives the XCDs), so a
-    // graph's h rows are gathered through one L2 only.  Affinity only; any placement is correct.
-    // Fewer than 8 graphs: some XCD would own none and idle, so every block then takes a slice of ALL lists.
-    const bool spread = L.num_graphs < 8;
-    const int xcd = blockIdx.x & 7;
-    const int jb = spread ? (int)blockIdx.x : (int)(blockIdx.x >> 3);                           // this group's blocks: jb of nloc
-    const int nloc = spread ? (int)gridDim.x : (int)((gridDim.x + 7 - xcd) >> 3);
-    const int g0 = spread ? 0 : eh_xcd_first_graph(xcd, L.num_graphs);
-    const int g1 = spread ? L.num_graphs : eh_xcd_first_graph(xcd + 1, L.num_graphs);
-    const int32_t* clong = counter + EH_HC_LONG(L.num_graphs);
-    int total = 0, nlong = 0;                                         // heavy / long rows of this XCD's graphs
-    for (int gg = g0; gg < g1; ++gg) { total += counter[gg]; nlong += clong[gg]; }
-    // work of this block: first its share of the XCD's long rows (blocks are dispatched in index order, so the rows
-    // that take longest start first), then its share of the other heavy rows.  Both are concatenations of per-graph
-    // lists, walked with a cursor (indices only grow).
-    const int first = nlong > jb ? (nlong - jb + nloc - 1) / nloc : 0;   // long rows this block takes
-    int gcur = g0, gbase = 0;
-    for (int round = 0;; ++round) {
-        int idx, g;                                                  // the list position names the graph: no look-up by node
-        if (round < first) {
-            const int li = jb + round * nloc;
-            while (li >= gbase + clong[gcur]) { gbase += clong[gcur]; ++gcur; }
-            g = gcur;
-            idx = L.node_ptr[gcur + 1] - 1 - (li - gbase);
-            if (round + 1 == first) { gcur = g0; gbase = 0; }       // the cursor starts over for the second list
-        } else {
-            const int li = jb + (round - first) * nloc;
-            if (li >= total) break;
-            while (li >= gbase + counter[gcur]) { gbase += counter[gcur]; ++gcur; }
-            g = gcur;
-            idx = L.node_ptr[gcur] + (li - gbase);
-        }
-        const int node = heavy_pg[idx], cidx = idx;
-        const int node0 = L.node_ptr[g];
-        const int stride = L.adj_stride[g];
-        const uint32_t* rowp = adj + L.adj_ptr[g] + (int64_t)(node - node0) * stride;
-        f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
-        float m = -1e30f, lsum = 0.f, mthr = -1e30f + EH_REF_SLACK;
-        {
-            // qt row of the gathered GEMM + the per-graph bias (time embedding / context terms)
-            f32x2 qb[EH_CPL / 2];
-            eh_load_cpl(q, qheavy + (size_t)cidx * H + head * 64 + c * EH_CPL);
-            eh_load_cpl(qb, qbias + (size_t)g * ldq + head * 64 + c * EH_CPL);
-#pragma unroll
-            for (int d = 0; d < EH_CPL / 2; ++d) { q[d] += qb[d]; acc[d] = f32x2{0.f, 0.f}; }
-            eh_scale_q_log2e(q);
-        }
-        for (int w0 = 0; w0 < stride; w0 += EH_HCHUNK) {
-            uint32_t w = (lane < EH_HCHUNK && w0 + lane < stride) ? rowp[w0 + lane] : 0u;
-            const int cnt = __popc(w);
-            int incl = cnt;
-            incl = eh_wave_scan_incl(incl);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (total == 0) continue;
-            int pos = incl - cnt;
-            const uint32_t jb = (uint32_t)(node0 + (w0 + lane) * 32);
-            while (w) { list[pos++] = (jb + (uint32_t)__ffs((int)w) - 1u) * 256u; w &= w - 1; }
-            if (lane < UN) list[total + lane] = (uint32_t)node * 256u;   // filler visits of the last step (masked)
-            EH_LDS_SYNC();
-            // HEADS >= 4: the head groups of a slot would gather the same bytes 4-8 times - go through LDS
-            if constexpr (HEADS >= 4) eh_walk_list_staged<HEADS>(list, total, hsrc, stage, q, lane, acc, m, mthr, lsum);
-            else eh_walk_list<HEADS>(list, total, hsrc, q, lane, acc, m, mthr, lsum);
-            EH_LDS_SYNC();                                      // the list is rewritten by the next chunk
-        }
-        eh_merge_slots<HEADS>(acc, m, lsum);
-        if (slot == 0) eh_store_cpl_scaled(zheavy + (size_t)cidx * H + head * 64 + c * EH_CPL, acc, 1.0f / (lsum + 1e-16f));
-    }
-}
-
 // --------------------------------------------------------------------------------------------
 // Fused layer: for one node tile (32 live nodes of one graph, one 512-thread block)
 //   A  qt   = Mcat h + qbias_g                      -> LDS            (MFMA, 2h column tiles over the 8 waves)
@@ -1218,7 +1022,6 @@ struct eh_layer_args {
     const float* Ocat; const float* obias0; const float* obias1;
     const float *w_ih, *w_hh, *b_ih, *b_hh;
     const float* cw0; const float* cbias;
-    const int32_t* heavy_slot; const float* zheavy;   // rows walked by k_attn_heavy (slot >= 0)
     const int32_t* idle;                               // kptr: tiles of graphs without active pairs exit (or null)
     const int32_t* crow; const float* cwgt; const int32_t* ccount;   // live rows (k_compact): node ids, weights, count per graph
     float* hnew; float* part;
@@ -1261,6 +1064,7 @@ extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) 
 // that produces them (with the per-fragment splits 37 % of the kernel's vector instructions were operand splits).
 // One kernel for every batch size: a graph's result does not depend on the batch it is sampled in.
 // --------------------------------------------------------------------------------------------
+#define EH_WIN 192                                 // entries of a wave's neighbour list window (multiple of every step size 4 / 8)
 #define EH_SPL (3 * EH_W3_PLANE)                   // dwords of a 32 x 64 tile kept as three bf16 planes in fragment order
 
 // operand group I (k = 32 * (lane >> 5) + 8 I + j) of a 64-deep chunk: A from two fp32 quads (split here), B from the
@@ -1331,8 +1135,8 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     constexpr int RMIN = 16 * 32 * 32;                             // the 16 partial tiles of phase C
     constexpr int R1 = (32 * QP > RMIN) ? 32 * QP : RMIN;
     static_assert(8192 + EH_SPL <= R1, "gate exchange + conv / h' planes fit behind each other");
-    static_assert(EH_SPL <= EH_TSZ + 8 * 4 * EH_HEAVY_DEG, "the h planes fit into the staging tiles + neighbour lists");
-    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 8 * 4 * EH_HEAVY_DEG + 96];
+    static_assert(EH_SPL <= EH_TSZ + 8 * EH_WIN, "the h planes fit into the staging tiles + neighbour lists");
+    __shared__ __attribute__((aligned(16))) float lds[R1 + EH_TSZ + 8 * EH_WIN + 96];
     float* qz = lds;                    // [32][QP]       qt, then z in place                     (phases A-C)
     float* pt = lds;                    // [16][32][32]   partial tiles (K eighth, column tile)   (phase C end)
     float* xg = lds;                    // [4][2][16][64] GRU gate exchange                       (phase D)
@@ -1344,8 +1148,8 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     // neighbour lists (idl), neither of which exists outside phase B: the planes are written again after it.
     unsigned* hpl = reinterpret_cast<unsigned*>(lds + R1);
     float* hp = lds + R1;               // [8 waves][4][68] staging tiles of the walk (phase B)
-    int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [8 waves][4 targets][EH_HEAVY_DEG] neighbour row offsets
-    int* nl = idl + 8 * 4 * EH_HEAVY_DEG;                          // [32] node id of every row of the tile
+    int* idl = reinterpret_cast<int*>(lds + R1 + EH_TSZ);          // [8 waves][EH_WIN] neighbour row offsets: a window of the wave's visit stream
+    int* nl = idl + 8 * EH_WIN;                          // [32] node id of every row of the tile
     float* wl = reinterpret_cast<float*>(nl + 32);                 // [32] weight of every row (size of its class)
     int* dl = nl + 64;                                             // [32] degree of every row
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1369,7 +1173,6 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     const int mynid = a.crow[cbase + (r < rows ? r : rows - 1)];           // every wave: lane l holds the node of row l & 31
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }
     const int mydeg = a.deg[mynid];
-    const int myhs = a.heavy_slot[mynid];
     if (tid < 32) dl[tid] = mydeg;
 
     // ---- phase 0 loads: the h tile, one 16-byte piece per thread
@@ -1378,14 +1181,14 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     // A wave walks 4 of the tile's rows; its time is the SUM of their degrees, so the rows are dealt to the waves
     // longest-first in snake order (rank the 32 walk lengths, wave w takes ranks 8k + w on even k and 8k + 7 - w on
     // odd k).  Every wave computes the same assignment from the same registers.
-    // The assignment depends on the step's degrees and heavy-row slots only, not on the layer: the first layer of a
+    // The assignment depends on the step's degrees only, not on the layer: the first layer of a
     // forward pass computes it (32 cross-lane compares per wave, a tenth of the kernel's vector instructions when every
     // layer did it) and leaves it in the workspace, the other layers read it back.
     int perm;                                                              // lane p: the row of rank p & 31
     if (a.perm_read) {
         perm = a.tperm[(size_t)tile * 32 + r];
     } else {
-        const int work = (r < rows && myhs < 0) ? mydeg : 0;              // heavy / absent rows are not walked here
+        const int work = (r < rows && mydeg <= EH_LONG_DEG) ? mydeg : 0;  // absent rows are not walked, long rows by all waves together
         int rank = 0;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -1403,13 +1206,12 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     const uint32_t* gadj = a.adj + L.adj_ptr[g];
     const bool mine4 = lane < 4 && trow4 < rows;
     const int nid4 = __shfl(mynid, trow4);                                // lane k < 4: node id of target k
-    const int hs4t = __shfl(myhs, trow4), dg4t = __shfl(mydeg, trow4);
-    const int hs4 = mine4 ? hs4t : -1;
+    const int dg4t = __shfl(mydeg, trow4);
     const int dg4 = mine4 ? dg4t : 0;
     uint32_t fw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool need = __builtin_amdgcn_readlane(dg4, k) > 0 && __builtin_amdgcn_readlane(hs4, k) < 0;
+        const bool need = __builtin_amdgcn_readlane(dg4, k) > 0 && __builtin_amdgcn_readlane(dg4, k) <= EH_LONG_DEG;
         fw[k] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid4, k) - node0) * stride + lane] : 0u;
     }
 
@@ -1438,70 +1240,32 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     }
     EH_BLOCK_SYNC();
 
-    // ---- phase B: attention of the light rows, z overwrites qt.
+    // ---- phase B: attention, z overwrites qt.
     // A wave owns 4 targets (dealt longest-first above) and walks them as ONE flat stream of neighbour visits: the
-    // decoded neighbour lists are concatenated in LDS (each padded to a whole step), so the gathers of the next step
-    // are in flight across target boundaries and the work of a wave is the SUM of its degrees, not 4 x the largest.
+    // decoded neighbour lists are concatenated (each padded to a whole step), so the gathers of the next step are in
+    // flight across target boundaries and the work of a wave is the SUM of its degrees, not 4 x the largest.  The stream
+    // passes through the wave's list in LDS in WINDOWS of EH_WIN entries (a multiple of every step size, so a window
+    // ends on a step boundary): four rows of up to 48 neighbours are one window, a row of 351 neighbours spans two - the
+    // walk's state (target, step, softmax sums) simply carries over.  Every row of the tile is walked here, whatever its
+    // degree: rounds 1-3 sent rows above 48 neighbours to a kernel of their own (one wave per row, fed by a gathered-row
+    // qt product and copied back into this tile), two more dependent launches per layer.
     // Lane = (slot, head, c): channels 8c..8c+7 of one head; HEADS < 8 runs 8/HEADS neighbours side by side (slots)
     // and merges their softmax states when the target ends.
     if (anynbr) {
         constexpr int NSLOT = eh_walk_cfg<HEADS>::NSLOT, U = eh_walk_cfg<HEADS>::U;
         constexpr int UN = eh_walk_cfg<HEADS>::UN;
-        static_assert(EH_HEAVY_DEG % UN == 0, "lists are padded to whole steps inside their EH_HEAVY_DEG slots");
+        constexpr int CAP = EH_WIN;
+        static_assert(CAP % UN == 0, "a window ends on a step boundary");
         const int wgrp = lane / EH_LG, wc = lane % EH_LG;
         const int slot = wgrp / HEADS, head = wgrp % HEADS;
-        uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * (4 * EH_HEAVY_DEG);
-        // decode the rows into ascending lists of neighbour-row byte offsets in LDS: the first 64 words of all 4 rows
-        // together (popcount + wave prefix sums, the scans interleaved), further words row by row
-        int wdeg = 0;             // lane k < 4: neighbours of target k walked here (0: isolated or heavy)
-        int total_steps = 0;      // wave-uniform
-        {
-            int cnt[4], incl[4];
+        uint32_t* flat = reinterpret_cast<uint32_t*>(idl) + wave * CAP;
+        // the padded stream: target k occupies positions [sk[k], sk[k] + pad(degree k))
+        const int wdeg = dg4 > EH_LONG_DEG ? 0 : dg4;     // lane k < 4: neighbours of target k walked in this wave's stream (0: isolated, absent or long)
+        int sk[5];
+        sk[0] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { cnt[k] = __popc(fw[k]); incl[k] = cnt[k]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) incl[k] = eh_wave_scan_incl(incl[k]);
-            int off = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int base = __builtin_amdgcn_readlane(incl[k], 63);
-                int pos = incl[k] - cnt[k];
-                uint32_t w = fw[k];
-                const int jb = node0 + lane * 32;
-                while (w) {
-                    if (pos < EH_HEAVY_DEG) flat[off + pos] = (uint32_t)(jb + __ffs((int)w) - 1) * 256u;
-                    ++pos;
-                    w &= w - 1;
-                }
-                if (stride > 64) {
-                    const bool need = __builtin_amdgcn_readlane(dg4, k) > 0 && __builtin_amdgcn_readlane(hs4, k) < 0;
-                    if (need) {
-                        const uint32_t* rowp = gadj + (int64_t)(__builtin_amdgcn_readlane(nid4, k) - node0) * stride;
-                        for (int w0 = 64; w0 < stride; w0 += 64) {
-                            uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
-                            const int c2 = __popc(w2);
-                            int in2 = c2;
-                            in2 = eh_wave_scan_incl(in2);
-                            int p2 = base + in2 - c2;
-                            const int jb2 = node0 + (w0 + lane) * 32;
-                            while (w2) {
-                                if (p2 < EH_HEAVY_DEG) flat[off + p2] = (uint32_t)(jb2 + __ffs((int)w2) - 1) * 256u;
-                                ++p2;
-                                w2 &= w2 - 1;
-                            }
-                            base += __builtin_amdgcn_readlane(in2, 63);
-                        }
-                    }
-                }
-                base = base < EH_HEAVY_DEG ? base : EH_HEAVY_DEG;
-                const int padded = (base + UN - 1) / UN * UN;
-                if (base + lane < padded) flat[off + base + lane] = (uint32_t)__builtin_amdgcn_readlane(nid4, k) * 256u;   // masked filler visits
-                if (lane == k) wdeg = base;
-                off += padded;
-                total_steps += padded / UN;
-            }
-        }
-        EH_LDS_SYNC();
+        for (int k = 0; k < 4; ++k) sk[k + 1] = sk[k] + (__builtin_amdgcn_readlane(wdeg, k) + UN - 1) / UN * UN;
+        const int slen = sk[4];                                  // wave-uniform
         {
             f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
             float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
@@ -1509,16 +1273,6 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
             for (int d = 0; d < EH_CPL / 2; ++d) { q[d] = f32x2{0.f, 0.f}; acc[d] = f32x2{0.f, 0.f}; }
             int k = -1, st = 0, nst = 0, dk = 0;        // wave-uniform cursor: target, step in target, steps, degree
             int krow = 0;                               // tile row of target k
-            // the row offsets of a step are read from the LDS list one step before its gathers are issued
-            // (otherwise every step exposes an LDS round trip: ds_read -> wait -> address -> loads)
-            auto offs_of = [&](int gs, uint32_t (&o)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
-            };
-            auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
-            };
             auto compute = [&](const eh_xr (&x)[U]) {
                 if (st == nst) {                         // next target with work
                     do {
@@ -1542,7 +1296,61 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
                         eh_store_cpl_scaled(qz + krow * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
                 }
             };
-            if (total_steps > 0) {
+#pragma unroll 1
+            for (int woff = 0; woff < slen; woff += CAP) {
+                // decode this window's part of the rows into ascending lists of neighbour-row byte offsets: the first 64
+                // words of a row come from fw (requested before phase A; read again for a later window), further words
+                // row by row.  An entry of rank p of target k sits at stream position sk[k] + p.
+                if (woff > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const bool need = __builtin_amdgcn_readlane(wdeg, kk) > 0 && sk[kk + 1] > woff;
+                        fw[kk] = (need && lane < stride) ? gadj[(int64_t)(__builtin_amdgcn_readlane(nid4, kk) - node0) * stride + lane] : 0u;
+                    }
+                }
+                int cnt[4], incl[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { cnt[kk] = __popc(fw[kk]); incl[kk] = cnt[kk]; }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) incl[kk] = eh_wave_scan_incl(incl[kk]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int dkk = __builtin_amdgcn_readlane(wdeg, kk);
+                    if (dkk == 0 || sk[kk + 1] <= woff || sk[kk] >= woff + CAP) continue;     // wave-uniform
+                    const int rel = sk[kk] - woff;                   // window position of the target's rank 0 (may be < 0)
+                    int base = __builtin_amdgcn_readlane(incl[kk], 63);
+                    int pos = rel + incl[kk] - cnt[kk];
+                    uint32_t w = fw[kk];
+                    const int jb = node0 + lane * 32;
+                    while (w) {
+                        if ((unsigned)pos < (unsigned)CAP) flat[pos] = (uint32_t)(jb + __ffs((int)w) - 1) * 256u;
+                        ++pos;
+                        w &= w - 1;
+                    }
+                    if (stride > 64) {
+                        const uint32_t* rowp = gadj + (int64_t)(__builtin_amdgcn_readlane(nid4, kk) - node0) * stride;
+                        for (int w0 = 64; w0 < stride; w0 += 64) {
+                            uint32_t w2 = (w0 + lane < stride) ? rowp[w0 + lane] : 0u;
+                            const int c2 = __popc(w2);
+                            int in2 = c2;
+                            in2 = eh_wave_scan_incl(in2);
+                            int p2 = rel + base + in2 - c2;
+                            const int jb2 = node0 + (w0 + lane) * 32;
+                            while (w2) {
+                                if ((unsigned)p2 < (unsigned)CAP) flat[p2] = (uint32_t)(jb2 + __ffs((int)w2) - 1) * 256u;
+                                ++p2;
+                                w2 &= w2 - 1;
+                            }
+                            base += __builtin_amdgcn_readlane(in2, 63);
+                        }
+                    }
+                    // masked filler visits up to the whole step (ranks dkk .. pad - 1)
+                    const int pf = rel + dkk + lane;
+                    if (dkk + lane < sk[kk + 1] - sk[kk] && (unsigned)pf < (unsigned)CAP)
+                        flat[pf] = (uint32_t)__builtin_amdgcn_readlane(nid4, kk) * 256u;
+                }
+                EH_LDS_SYNC();
+                const int total_steps = ((slen - woff < CAP) ? slen - woff : CAP) / UN;      // steps of this window
                 if constexpr (HEADS >= 4) {
                     // The neighbour rows of a step go through a wave-private LDS tile (see eh_walk_list_staged: one
                     // load instruction per four rows instead of eight per-lane gathers of the same bytes).  The tiles
@@ -1594,7 +1402,16 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
                     }
                 } else {
                     // HEADS <= 2: a load instruction already brings 4-8 different rows (one per slot): gather directly,
-                    // two register sets, the gathers one step ahead of their use; one loop exit (see above)
+                    // two register sets, the gathers one step ahead of their use; one loop exit (see above).  The row
+                    // offsets of a step are read from the list one step before its gathers are issued.
+                    auto offs_of = [&](int gs, uint32_t (&o)[U]) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) o[u] = flat[(gs * U + u) * NSLOT + slot];
+                    };
+                    auto issue = [&](const uint32_t (&o)[U], eh_xr (&x)[U]) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) eh_gather(x[u], a.hprev, o[u], wc);
+                    };
                     constexpr int EH_PF = 2;
                     eh_xr xs[EH_PF][U];
                     uint32_t on[U];
@@ -1617,27 +1434,99 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
                         }
                     }
                 }
+                EH_LDS_SYNC();                                   // the next window rewrites the list
             }
         }
-        // targets not walked here: isolated -> z = 0, heavy -> k_attn_heavy computed z.  16 lanes per target, one 16-byte
-        // piece of every head each; all loads of a row in flight before its stores
+        // ---- long rows (more than EH_LONG_DEG neighbours): walked by ALL eight waves, wave w taking the words w, w + 8, ..
+        // of the bit row (a cyclic deal: hubs' neighbours cluster), each with its own softmax state; the eight states are
+        // merged in a fixed order by one wave.  One such row in a wave's stream would hold the tile for its whole length
+        // while seven waves wait (polblogs: 351 neighbours against ~110 visits per wave).
+        {
+            uint32_t lmask = (uint32_t)__ballot(r < rows && mydeg > EH_LONG_DEG);      // block-uniform: every wave holds all rows
+            constexpr int CAPL = CAP - UN;                                             // room for the fillers of the last step
+            constexpr int PS = H + 2 * HEADS;                                          // floats of a wave's state: sums, reference, weight total
+            static_assert(7 * PS <= EH_TSZ + 8 * EH_WIN, "seven states fit into the staging tiles + lists");
+            float* stage = hp + wave * (UN * EH_SGP);
+            int jl = 0;
+            while (lmask) {
+                const int lr = __ffs((int)lmask) - 1;
+                lmask &= lmask - 1;
+                const int lnid = __builtin_amdgcn_readlane(mynid, lr);
+                f32x2 q[EH_CPL / 2], acc[EH_CPL / 2];
+                float mrun = -1e30f, lrun = 0.f, mthr = -1e30f + EH_REF_SLACK;
+                eh_load_cpl(q, qz + lr * QP + head * 64 + wc * EH_CPL);
+                eh_scale_q_log2e(q);
+#pragma unroll
+                for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = f32x2{0.f, 0.f};
+                const uint32_t* rowp = gadj + (int64_t)(lnid - node0) * stride;
+                for (int w0 = 0; w0 < stride; w0 += 512) {
+                    const int wi = w0 + 8 * lane + wave;                               // lane i: word w0 + 8 i + wave
+                    uint32_t wd = wi < stride ? rowp[wi] : 0u;
+                    const int cnt = __popc(wd);
+                    int incl = cnt;
+                    incl = eh_wave_scan_incl(incl);
+                    if (__builtin_amdgcn_readlane(incl, 63) == 0) continue;
+                    int done = 0, before = 0;                                          // lanes / neighbours already walked
+                    while (done < 64) {
+                        // the longest run of lanes whose neighbours fit into the list
+                        const int fit = __popcll(__ballot(incl - before <= CAPL));     // incl is monotone: lanes [0, fit)
+                        const int n = __builtin_amdgcn_readlane(incl, fit - 1) - before;
+                        if (n > 0) {
+                            if (lane >= done && lane < fit) {
+                                int pos = incl - cnt - before;
+                                const uint32_t jb = (uint32_t)(node0 + wi * 32);
+                                uint32_t w = wd;
+                                while (w) { flat[pos++] = (jb + (uint32_t)__ffs((int)w) - 1u) * 256u; w &= w - 1; }
+                            }
+                            if (lane < UN) flat[n + lane] = (uint32_t)lnid * 256u;    // masked filler visits of the last step
+                            EH_LDS_SYNC();
+                            if constexpr (HEADS >= 4) eh_walk_list_staged<HEADS>(flat, n, a.hprev, stage, q, lane, acc, mrun, mthr, lrun);
+                            else eh_walk_list<HEADS>(flat, n, a.hprev, q, lane, acc, mrun, mthr, lrun);
+                            EH_LDS_SYNC();
+                        }
+                        done = fit;
+                        before += n;
+                    }
+                }
+                eh_merge_slots<HEADS>(acc, mrun, lrun);
+                const int owner = jl & 7;
+                EH_BLOCK_SYNC();                                   // every wave is done with its staging tile and its list
+                if (wave != owner && slot == 0) {
+                    float* xs = hp + ((wave - owner - 1) & 7) * PS;
+                    eh_store_cpl_scaled(xs + head * 64 + wc * EH_CPL, acc, 1.0f);
+                    if (wc == 0) { xs[H + head] = mrun; xs[H + HEADS + head] = lrun; }
+                }
+                EH_BLOCK_SYNC();
+                if (wave == owner && slot == 0) {
+#pragma unroll 1
+                    for (int p = 0; p < 7; ++p) {
+                        const float* xs = hp + p * PS;
+                        f32x2 pa[EH_CPL / 2];
+                        eh_load_cpl(pa, xs + head * 64 + wc * EH_CPL);
+                        const float pm = xs[H + head], pl = xs[H + HEADS + head];
+                        const float mm = fmaxf(mrun, pm);
+                        const float sa = eh_exp2(mrun - mm), sb = eh_exp2(pm - mm);
+                        const f32x2 sa2 = f32x2{sa, sa}, sb2 = f32x2{sb, sb};
+#pragma unroll
+                        for (int d = 0; d < EH_CPL / 2; ++d) acc[d] = acc[d] * sa2 + pa[d] * sb2;
+                        lrun = lrun * sa + pl * sb;
+                        mrun = mm;
+                    }
+                    eh_store_cpl_scaled(qz + lr * QP + head * 64 + wc * EH_CPL, acc, 1.0f / (lrun + 1e-16f));
+                }
+                EH_BLOCK_SYNC();                                   // the states are read: the next long row may decode
+                ++jl;
+            }
+        }
+        // targets without neighbours (isolated or absent rows): z = 0.  16 lanes per target, one 16-byte piece of every head
         {
             const int tg = lane >> 4, c16 = lane & 15;
-            const int tdeg = __shfl(wdeg, tg);
-            const int hslot = __shfl(hs4, tg);
+            const int tdeg = __shfl(dg4, tg);
             const int trow = __shfl(trow4, tg);
             if (tdeg == 0) {
                 float* zrow = qz + trow * QP + c16 * 4;
-                f32x4 zv[HEADS];
 #pragma unroll
-                for (int h = 0; h < HEADS; ++h) zv[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (hslot >= 0) {
-                    const f32x4* zp = reinterpret_cast<const f32x4*>(a.zheavy + (size_t)hslot * H + c16 * 4);
-#pragma unroll
-                    for (int h = 0; h < HEADS; ++h) zv[h] = zp[h * 16];
-                }
-#pragma unroll
-                for (int h = 0; h < HEADS; ++h) *reinterpret_cast<f32x4*>(zrow + h * 64) = zv[h];
+                for (int h = 0; h < HEADS; ++h) *reinterpret_cast<f32x4*>(zrow + h * 64) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -1917,7 +1806,7 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
                                const uint32_t* adj, const int32_t* deg, const int32_t* d0, const int32_t* t_graph,
                                int t_shared, const uint8_t* flags, const int32_t* act_nodes, const int32_t* kptr,
                                const edgehip_counts* counts, float* node_repr, float* h_out, const eh_ws& w,
-                               hipStream_t s, bool counters_cleared = false) {
+                               hipStream_t s) {
     eh_fold_map fm = eh_make_fold_map(P);
     const int B = L->num_graphs, Nn = L->num_nodes, NT = L->num_tiles;
     if (B == 0 || Nn == 0) return EDGEHIP_OK;
@@ -1928,20 +1817,19 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
     for (int l = 0; l < P->num_layers; ++l) hmax = P->heads[l] > hmax ? P->heads[l] : hmax;
     const int ldq = hmax * 64;
 
-    // heavy and long rows per graph start at zero (the fused reverse step clears them in its selection launch)
-    if (!counters_cleared) (void)hipMemsetAsync(w.heavy_count, 0, EH_HC_INTS(B) * 4, s);
     {
         eh_prep_args pa = {};
         pa.max_degree = P->max_degree; pa.at = folded + fm.nin_at; pa.a0 = folded + fm.nin_a0; pa.as = folded + fm.nin_as;
         pa.deg = deg; pa.d0 = d0; pa.flags = flags; pa.idle = idle; pa.h0 = w.hA; pa.part = w.part;
-        pa.heavy_count = w.heavy_count; pa.heavy_slot = w.heavy_slot; pa.heavy_pg = w.heavy_pg;
         pa.dedupe = h_out ? 0 : 1; pa.crow = w.crow; pa.cwgt = w.cwgt; pa.rep_of = w.rep_of; pa.ccount = w.ccount;
         pa.tile_blocks = tile_blocks;
         EH_PROF(EH_K_NODE_IN, s, hipLaunchKernelGGL(k_step_prepare, dim3(tile_blocks + B), dim3(256), 0, s, *L, pa));
     }
     float* hcur = w.hA;
     float* hnext = w.hB;
-    for (int l = 0; l <= P->num_layers; ++l) {
+    // per-graph update of layer l (context chain, per-graph bias rows): one launch before every layer, and one after
+    // the last (context for the node tail)
+    auto update_args = [&](int l) {
         eh_layer_ptrs lp = {};
         if (l < P->num_layers) {
             const eh_fold_layer& f = fm.layer[l];
@@ -1954,10 +1842,14 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         ua.ctx_in = w.ctx + (size_t)((l + 1) & 1) * (B + 1) * 64; ua.ctx = w.ctx + (size_t)(l & 1) * (B + 1) * 64;
         ua.qbias = w.qbias; ua.ldq = ldq; ua.obias0 = w.obias0; ua.obias1 = w.obias1; ua.cbias = w.cbias;
         ua.idle = idle; ua.ccount = w.ccount;
-        if (l == P->num_layers) {
+        return ua;
+    };
+    for (int l = 0; l <= P->num_layers; ++l) {
+        {
+            eh_update_args ua = update_args(l);
             EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_graph_update, dim3(B * EH_GU_PARTS), dim3(256), 0, s, *L, *P, ua));
-            break;
         }
+        if (l == P->num_layers) break;
         const int h = P->heads[l];
         eh_layer_args la = {};
         la.adj = adj; la.hprev = hcur; la.deg = deg;
@@ -1965,38 +1857,10 @@ static int eh_gnn_forward_impl(const edgehip_layout* L, const edgehip_gnn_params
         la.Ocat = folded + fm.layer[l].pOcat; la.obias0 = w.obias0; la.obias1 = w.obias1;
         la.w_ih = folded + fm.pWih; la.w_hh = folded + fm.pWhh; la.b_ih = P->gru_b_ih; la.b_hh = P->gru_b_hh;
         la.cw0 = folded + fm.pCw0; la.cbias = w.cbias; la.hnew = hnext; la.part = w.part;
-        la.heavy_slot = w.heavy_slot; la.zheavy = w.Z; la.idle = idle;
+        la.idle = idle;
         la.crow = w.crow; la.cwgt = w.cwgt; la.ccount = w.ccount;
         la.tperm = w.tperm; la.perm_read = l > 0 ? 1 : 0;
         la.count_rows = eh_prof_on() ? 1 : 0;
-        // per-graph update of this layer and qt of the heavy rows (gathered-row GEMM into the compact buffer
-        // w.Qt) in ONE launch: they are independent, and each alone is a latency-bound launch
-        {
-            eh_hq_args d;
-            d.A = hcur; d.W = folded + fm.layer[l].pMcat; d.Y = w.Qt; d.H = h * 64;
-            d.seg_ptr = L->node_ptr; d.seg_lo = w.heavy_count; d.seg_hi = w.heavy_count + EH_HC_LONG(B); d.row_of = w.heavy_pg;
-            d.nseg = B;
-            // grid for the upper bound Nn rows; the waves past the listed rows leave at once
-            const int gx = (int)((((int64_t)Nn + 31) / 32 + 3) / 4);
-            const int ngt = h * 2;                                  // 32-column groups
-            int split = (2048 + gx - 1) / gx;
-            split = split < 1 ? 1 : (split > ngt ? ngt : split);
-            const int per = (ngt + split - 1) / split;
-            split = (ngt + per - 1) / per;
-            const int nbu = B * EH_GU_PARTS;
-            EH_PROF(EH_K_GRAPH_UPDATE, s, hipLaunchKernelGGL(k_update_and_heavy_qt, dim3(nbu + gx * split), dim3(256), 0, s, *L, *P, ua,
-                               nbu, d, gx, per));
-        }
-#ifndef EH_HEAVY_BLOCKS
-#define EH_HEAVY_BLOCKS 16384
-#endif
-        const int hb = Nn < EH_HEAVY_BLOCKS ? Nn : EH_HEAVY_BLOCKS;          // single-wave blocks
-        switch (h) {
-            case 8: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<8>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
-            case 4: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<4>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
-            case 2: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<2>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
-            default: EH_PROF(EH_K_ATTN, s, hipLaunchKernelGGL(k_attn_heavy<1>, dim3(hb), dim3(64), 0, s, *L, adj, hcur, w.Qt, w.qbias, ldq, w.heavy_count, w.heavy_pg, w.Z)); break;
-        }
         switch (h) {
             case 8: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<8>, dim3(NT), dim3(512), 0, s, *L, la)); break;
             case 4: EH_PROF(EH_K_LAYER, s, hipLaunchKernelGGL(k_layer<4>, dim3(NT), dim3(512), 0, s, *L, la)); break;
@@ -2329,33 +2193,33 @@ extern "C" int edgehip_edge_ce_loss(const edgehip_layout* L, const edgehip_gnn_p
 // --------------------------------------------------------------------------------------------
 // measurement hook: what the LAST edgehip_sample_step on this workspace worked on (bench.py prints the profile of
 // the timed trajectory with it).  out[8] int64 on the device: active nodes K, active pairs A, graphs with >= 2
-// active nodes (the others were skipped), live node rows after the isolated-class compaction, heavy rows, long
-// rows, sum of degrees of the state the step started from (= 2 E_t), nodes in the non-idle graphs.
+// active nodes (the others were skipped), live node rows after the isolated-class compaction, rows of the non-idle
+// graphs with more than 48 neighbours, rows with more than EH_LONG_DEG (walked by a whole tile together), sum of degrees of the state the step started from (= 2 E_t), nodes in the non-idle graphs.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_step_stats(edgehip_layout L, const int32_t* __restrict__ kptr,
-                                                    const int32_t* __restrict__ ccount, const int32_t* __restrict__ heavy,
+                                                    const int32_t* __restrict__ ccount,
                                                     const int32_t* __restrict__ deg, const edgehip_counts* __restrict__ counts,
                                                     long long* __restrict__ out) {
-    __shared__ long long red[3][256];
+    __shared__ long long red[6][256];
     const int tid = threadIdx.x;
     long long act = 0, live = 0, dsum = 0, nodes = 0, nheavy = 0, nlong = 0;
     for (int g = tid; g < L.num_graphs; g += 256)
-        if (kptr[g + 1] - kptr[g] >= 2) {
-            act += 1; live += ccount[g]; nodes += L.node_ptr[g + 1] - L.node_ptr[g];
-            nlong += heavy[EH_HC_LONG(L.num_graphs) + g]; nheavy += heavy[g] + heavy[EH_HC_LONG(L.num_graphs) + g];
-        }
-    for (int i = tid; i < L.num_nodes; i += 256) dsum += deg[i];
-    red[0][tid] = act; red[1][tid] = live; red[2][tid] = dsum;
-    __shared__ long long rn[256], rh[256], rl[256];
-    rn[tid] = nodes; rh[tid] = nheavy; rl[tid] = nlong;
+        if (kptr[g + 1] - kptr[g] >= 2) { act += 1; live += ccount[g]; nodes += L.node_ptr[g + 1] - L.node_ptr[g]; }
+    for (int i = tid; i < L.num_nodes; i += 256) {
+        const int d = deg[i], g = L.node_graph[i];
+        dsum += d;
+        if (kptr[g + 1] - kptr[g] >= 2) { nheavy += d > EH_HEAVY_DEG ? 1 : 0; nlong += d > EH_LONG_DEG ? 1 : 0; }
+    }
+    red[0][tid] = act; red[1][tid] = live; red[2][tid] = dsum; red[3][tid] = nodes; red[4][tid] = nheavy; red[5][tid] = nlong;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
-        if (tid < d) { red[0][tid] += red[0][tid + d]; red[1][tid] += red[1][tid + d]; red[2][tid] += red[2][tid + d]; rn[tid] += rn[tid + d]; rh[tid] += rh[tid + d]; rl[tid] += rl[tid + d]; }
+        if (tid < d)
+            for (int k = 0; k < 6; ++k) red[k][tid] += red[k][tid + d];
         __syncthreads();
     }
     if (tid == 0) {
         out[0] = counts->k_total; out[1] = counts->a_total; out[2] = red[0][0]; out[3] = red[1][0];
-        out[4] = rh[0]; out[5] = rl[0]; out[6] = red[2][0]; out[7] = rn[0];
+        out[4] = red[4][0]; out[5] = red[5][0]; out[6] = red[2][0]; out[7] = red[3][0];
     }
 }
 
@@ -2366,7 +2230,7 @@ extern "C" int edgehip_prof_step_stats(const edgehip_layout* L, const edgehip_gn
     EH_CHECK_ARG(L && ws && counts && out_dev);
     eh_ws w = eh_carve(L, P, ws);
     if (ws_bytes < w.bytes) return EDGEHIP_ERR_WORKSPACE;
-    hipLaunchKernelGGL(k_step_stats, dim3(1), dim3(256), 0, eh_stream(stream), *L, w.kptr, w.ccount, w.heavy_count, w.deg, counts,
+    hipLaunchKernelGGL(k_step_stats, dim3(1), dim3(256), 0, eh_stream(stream), *L, w.kptr, w.ccount, w.deg, counts,
                        reinterpret_cast<long long*>(out_dev));
     EH_LAUNCH_CHECK();
     return EDGEHIP_OK;
@@ -2435,14 +2299,14 @@ extern "C" int edgehip_sample_step(const edgehip_layout* L, const edgehip_gnn_pa
     hipStream_t s = eh_stream(stream);
     rc = edgehip_degree_from_adj(L, adj, w.deg, stream);
     if (rc) return rc;
-    // the selection launch also writes t for every graph and clears the heavy-row counters of the forward pass
+    // the selection launch also writes t for every graph
     rc = eh_active_select_step(L, d0, w.deg, t, w.t_graph, post_table, nmax, u_node, rng, gumbel_lut, w.flags,
-                               w.act_nodes, w.act_count, w.heavy_count, (int)EH_HC_INTS(L->num_graphs), s);
+                               w.act_nodes, w.act_count, nullptr, 0, s);
     if (rc) return rc;
     rc = edgehip_active_offsets(L, w.act_count, w.kptr, w.aptr, w.tptr, counts, stream);
     if (rc) return rc;
     rc = eh_gnn_forward_impl(L, P, folded, adj, w.deg, d0, w.t_graph, 1, w.flags, w.act_nodes, w.kptr, counts,
-                             w.node_repr, nullptr, w, s, true);
+                             w.node_repr, nullptr, w, s);
     if (rc) return rc;
     return edgehip_edge_resample(L, P, folded, w.node_repr, w.act_nodes, w.kptr, w.aptr, w.tptr, counts, nullptr, 0,
                                  u_pair, rng, t, gumbel_lut, adj, nullptr, nullptr, 0, stream);

@@ -45,7 +45,7 @@ def _function_ranges(lines, prefix):
 
 def test_bank_masked_dpp_adds_keep_their_wait_states(isa):
     sites = [i for i, ln in enumerate(isa) if ln.startswith('v_add_f32_dpp') and 'bank_mask:0x5' in ln]
-    assert len(sites) >= 2                                     # k_layer<8> and k_attn_heavy<8> at least
+    assert len(sites) >= 2                                     # k_layer<8>: the stream walk and the long-row walk
     for i in sites:
         m = re.match(r'v_add_f32_dpp (v\d+), (v\d+), (v\d+) row_shl:4 row_mask:0xf bank_mask:0x5$', isa[i])
         assert m, isa[i]

@@ -108,7 +108,7 @@ def test_network_forward_with_sharp_attention_vs_oracle(graph):
     (csrc/gnn.hip: eh_walk_step).  Random-init weights give scores within a few units of each other, so the move is
     only taken at a row's first step; here query and key weights are scaled by 20 so that the scores of one row span
     up to ~140 units and the reference has to move in mid-row: on the polblogs-shaped graph the CPU oracle counts
-    ~1 400 such moves in the 8-head layer (~260 of them on heavy rows, walked by k_attn_heavy) and ~400 in the
+    ~1 400 such moves in the 8-head layer (~260 of them on rows above 48 neighbours) and ~400 in the
     one-head layer.  The ragged graphs cover the short rows (spread up to ~90 units inside a row's first steps)."""
     heads = (8, 1)
     graphs = cases.ragged_graphs(5) if graph == 'ragged' else cases.polblogs_graph(0)

@@ -9,5 +9,5 @@ for P in "$P1" "$P3"; do
   i=$((i+1))
 done
 cd $ROOT
-for i in 1 2; do python3 tools/pmc_reduce.py $OUT/st_p$i k_layer k_attn_heavy k_pair k_tail k_select k_update_and k_step_prepare k_row_popcount; done
+for i in 1 2; do python3 tools/pmc_reduce.py $OUT/st_p$i k_layer k_graph_update k_pair k_tail k_select k_graph_update k_step_prepare k_row_popcount; done
 rm -rf $OUT/st_p1 $OUT/st_p2

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 def main():
     d = sys.argv[1]
-    want = sys.argv[2:] or ['k_layer', 'k_attn_heavy']
+    want = sys.argv[2:] or ['k_layer', 'k_graph_update']
     acc = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         with open(f) as fh:

@@ -10,5 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 P="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 timeout -s KILL 200 rocprofv3 --pmc $P --output-format csv -d $OUT/${TAG}_sqp -o p -- python3 $ROOT/tools/kbench.py --t 100 --reps 4 > /dev/null 2>&1
 cd $ROOT
-python3 tools/pmc_reduce.py $OUT/${TAG}_sqp k_layer k_attn_heavy k_update | tee $OUT/${TAG}_sq_counters.txt
+python3 tools/pmc_reduce.py $OUT/${TAG}_sqp k_layer k_graph_update | tee $OUT/${TAG}_sq_counters.txt
 rm -rf $OUT/${TAG}_sqp

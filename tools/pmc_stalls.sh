@@ -15,6 +15,6 @@ for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
 done
 cd $ROOT
-for i in 1 2 3; do python3 tools/pmc_reduce.py $OUT/stall_p$i k_layer k_attn_heavy; done > $OUT/r3_pmc_stalls.txt
+for i in 1 2 3; do python3 tools/pmc_reduce.py $OUT/stall_p$i k_layer k_graph_update; done > $OUT/r3_pmc_stalls.txt
 rm -rf $OUT/stall_p1 $OUT/stall_p2 $OUT/stall_p3
 cat $OUT/r3_pmc_stalls.txt
