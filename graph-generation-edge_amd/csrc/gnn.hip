@@ -533,11 +533,62 @@ struct eh_update_args {
     const int32_t* idle; const int32_t* ccount;
 };
 
-// NW waves per block.  TAIL = false: one of EH_GU_PARTS blocks of a graph (k_graph_update).  TAIL = true: the last tile
-// of graph g to finish inside k_layer runs the whole update (every part's share), `part` having been written by other
-// blocks of the SAME launch - it is read with agent-scope loads.  `sm`: 768 floats of LDS.  Outputs are bit-identical
-// between the two forms (the same sums in the same order).
-template <int NW, bool TAIL>
+// The update is a chain of dependent GEMVs on 64 / 256-vectors, one block of 256 threads per (graph, part): nothing but
+// latency.  Every stage requests ALL it reads in one go - its weights, its bias row, and for the last stage the three
+// output jobs together - so a stage costs one round trip (the bias rows used to be loaded behind the reduction: a
+// second, dependent trip per stage; 19.7 -> 13.9 us per launch, six launches per reverse step).  Measured and not
+// taken: all weights of the chain in registers from the start (412 per lane) is no faster alone (13.0 us) and costs
+// 5 % end to end - under the sampler's two streams such a block cannot start on a CU until both resident tiles of
+// the other stream's layer kernel have left it; at 140 registers it follows the first wave that leaves.
+// Thread layout of a GEMV as in gemv.h (16 lanes per output row, one float4 per lane and 64-wide chunk, outputs
+// o = first + 16 pass + 4 wave + sub): the arithmetic of every output is the same as eh_block_gemv's.
+template <int KC, bool TWO, int NP>          // KC 64-wide chunks of the first operand, NP passes of 16 outputs
+struct eh_gemv_regs {
+    f32x4 w1[NP][KC];
+    f32x4 w2[TWO ? NP : 1];
+    float bias[NP];
+};
+template <int KC, bool TWO, int NP>
+__device__ static inline void eh_gemv_load(eh_gemv_regs<KC, TWO, NP>& R, const float* __restrict__ W1, int ld1,
+                                           const float* __restrict__ W2, int ld2, const float* __restrict__ bias,
+                                           int first, int count) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, kq = lane & 15;
+    const int o0 = first + 4 * wave + sub;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int o = o0 + 16 * p;
+        const int oc = o < first + count ? o : first;             // clamp: a valid row, result discarded
+#pragma unroll
+        for (int j = 0; j < KC; ++j) R.w1[p][j] = *reinterpret_cast<const f32x4*>(W1 + (size_t)oc * ld1 + 64 * j + 4 * kq);
+        if (TWO) R.w2[p] = *reinterpret_cast<const f32x4*>(W2 + (size_t)oc * ld2 + 4 * kq);
+        R.bias[p] = bias[oc];
+    }
+}
+template <int KC, bool TWO, int NP>
+__device__ static inline void eh_gemv_apply(const eh_gemv_regs<KC, TWO, NP>& R, const float* __restrict__ x1,
+                                            const float* __restrict__ x2, int first, int count, float* __restrict__ y, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, kq = lane & 15;
+    f32x4 xa[KC], xb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) xa[j] = *reinterpret_cast<const f32x4*>(x1 + 64 * j + 4 * kq);
+    if (TWO) xb = *reinterpret_cast<const f32x4*>(x2 + 4 * kq);
+    const int o0 = first + 4 * wave + sub;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int o = o0 + 16 * p;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            s += R.w1[p][j][0] * xa[j][0] + R.w1[p][j][1] * xa[j][1] + R.w1[p][j][2] * xa[j][2] + R.w1[p][j][3] * xa[j][3];
+        if (TWO) s += R.w2[p][0] * xb[0] + R.w2[p][1] * xb[1] + R.w2[p][2] * xb[2] + R.w2[p][3] * xb[3];
+        s = eh_row16_sum(s);
+        if (kq == 0 && o < first + count) {
+            s += R.bias[p];
+            y[o] = act ? eh_silu(s) : s;
+        }
+    }
+}
+
 __device__ static inline void eh_graph_update_body(float* __restrict__ sm, const edgehip_layout& L, const edgehip_gnn_params& P, int l, const eh_layer_ptrs& lp,
                                                       const float* __restrict__ part, const float* __restrict__ te /*[T][L][64]*/,
                                                       const int32_t* __restrict__ t_graph, int te_shared, const float* __restrict__ ctx_in, float* __restrict__ ctx, float* __restrict__ qbias,
@@ -548,15 +599,48 @@ __device__ static inline void eh_graph_update_body(float* __restrict__ sm, const
     const int tid = threadIdx.x;
     if (eh_graph_idle(idle, g)) return;
     const int n = L.node_ptr[g + 1] - L.node_ptr[g];
+    const bool outputs = l < P.num_layers;                           // block-uniform
+    eh_gemv_regs<4, false, 4> Rc2;                                   // context.2   256 -> 64
+    eh_gemv_regs<1, false, 16> Rg0;                                  // global.0     64 -> 256
+    eh_gemv_regs<4, false, 4> Rg2;                                   // global.2    256 -> 64
+    eh_gemv_regs<1, true, 8> Rq;                                     // this part's share of qbias: <= 128 outputs
+    const int per = ((lp.H / 16 + EH_GU_PARTS - 1) / EH_GU_PARTS) * 16;
+    const int qfirst = prt * per;
+    const int qcount = qfirst + per <= lp.H ? per : (lp.H > qfirst ? lp.H - qfirst : 0);
+    // the last job: cbias = context_b0 + context_w0[:, 64:128] . ctx (64 rows per part) and, on parts 1 and 2,
+    // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx  /  obias1 = bvbar + Vbbar . te + Vsum . ctx
+    static_assert(256 / EH_GU_PARTS == 64, "four passes of 16 outputs per job");
+    // heads <= 8 (eh_check_params): a part's share of qbias is at most 128 outputs = the eight passes of Rq
+    const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, kq = lane & 15;
+    const bool two = prt == 1 || prt == 2;                           // block-uniform
+    f32x4 wc[4], wt[4], wx[4];
+    float bc[4], bo[4];
+    auto load_last = [&]() {
+        eh_gemv_load(Rq, lp.Mtcat, 64, lp.Mcat, 64, lp.mbcat, qfirst, qcount);
+        const float* Wt = prt == 1 ? lp.skip_w + 64 : lp.Vbbar;      // . te
+        const float* Wx = prt == 1 ? lp.skip_w : lp.Vsum;            // . ctx (layer 0: zeros)
+        const int ldo = prt == 1 ? 128 : 64;
+        const float* ob = prt == 1 ? lp.skip_b : lp.bvbar;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int o = 16 * p + 4 * wave + sub;
+            wc[p] = *reinterpret_cast<const f32x4*>(P.context_w0 + 64 + (size_t)(prt * 64 + o) * 128 + 4 * kq);
+            bc[p] = P.context_b0[prt * 64 + o];
+            if (two) {
+                wt[p] = *reinterpret_cast<const f32x4*>(Wt + (size_t)o * ldo + 4 * kq);
+                wx[p] = *reinterpret_cast<const f32x4*>(Wx + (size_t)o * ldo + 4 * kq);
+                bo[p] = ob[o];
+            }
+        }
+    };
+    const float cold = (l > 0 && tid < 64) ? ctx_in[(size_t)g * 64 + tid] : 0.f;
     // l == 0: sums of k_step_prepare (h0) over all (static) tiles; l >= 1: weighted sums of the LIVE tiles of k_layer
     const int t0 = L.tile_ptr[g], t1 = (l == 0) ? L.tile_ptr[g + 1] : t0 + (ccount[g] + 31) / 32;
     const int width = (l == 0) ? 64 : 256;
     if (tid < width) {
-        // eight independent partial sums: the tile loads of a trip are all in flight together (a plain
-        // `s += part[..]` loop waits for every load in turn: ~40 L2 round trips per launch)
-        // 40 tiles per trip (a trip costs one round trip to memory - the sums were written by another kernel, possibly
-        // through another XCD's L2; the 39 tiles of a polblogs graph: ONE trip, it was two with 24); the sums keep the
-        // order of 8-tile trips: tile t0 + 8k + j goes to ps[j], k ascending (masked tiles add 0)
+        // 40 tiles per trip, all loads in flight together (a trip costs one round trip to memory - the sums were written
+        // by another kernel, possibly through another XCD's L2; the 39 tiles of a polblogs graph: ONE trip); the sums
+        // keep the order of 8-tile trips: tile t0 + 8k + j goes to ps[j], k ascending (masked tiles add 0)
         constexpr int TRIP = 40;
         float ps[8];
 #pragma unroll
@@ -564,10 +648,7 @@ __device__ static inline void eh_graph_update_body(float* __restrict__ sm, const
         for (int t = t0; t < t1; t += TRIP) {
             float x[TRIP];
 #pragma unroll
-            for (int j = 0; j < TRIP; ++j) {
-                if (TAIL) x[j] = (t + j < t1) ? __hip_atomic_load(part + (size_t)(t + j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                else x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
-            }
+            for (int j = 0; j < TRIP; ++j) x[j] = (t + j < t1) ? part[(size_t)(t + j) * 256 + tid] : 0.f;
 #pragma unroll
             for (int k = 0; k < TRIP / 8; ++k)
 #pragma unroll
@@ -578,86 +659,58 @@ __device__ static inline void eh_graph_update_body(float* __restrict__ sm, const
     }
     if (tid < 64) {
         zero64[tid] = 0.f;
-        if (l < P.num_layers) tev[tid] = te[((size_t)t_graph[te_shared ? 0 : g] * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
+        if (outputs) tev[tid] = te[((size_t)t_graph[te_shared ? 0 : g] * EDGEHIP_MAX_LAYERS + l) * 64 + tid];
     }
     __syncthreads();
     if (l == 0) {
         if (tid < 64) v[tid] = mean[tid];
     } else {
-        const float cold = tid < 64 ? ctx_in[(size_t)g * 64 + tid] : 0.f;      // in flight under the GEMV
-        eh_block_gemv<256, false, NW>(P.context_w2, 256, mean, nullptr, 0, nullptr, P.context_b2, 0, 64, v, 0);
+        eh_gemv_load(Rc2, P.context_w2, 256, nullptr, 0, P.context_b2, 0, 64);
+        eh_gemv_apply(Rc2, mean, nullptr, 0, 64, v, 0);
         __syncthreads();
         if (tid < 64) v[tid] += cold;
     }
     __syncthreads();
-    eh_block_gemv<64, false, NW>(P.global_w0, 64, v, nullptr, 0, nullptr, P.global_b0, 0, 256, hid, 1);
+    eh_gemv_load(Rg0, P.global_w0, 64, nullptr, 0, P.global_b0, 0, 256);
+    eh_gemv_apply(Rg0, v, nullptr, 0, 256, hid, 1);
     __syncthreads();
-    eh_block_gemv<256, false, NW>(P.global_w2, 256, hid, nullptr, 0, nullptr, P.global_b2, 0, 64, cn, 0);
+    eh_gemv_load(Rg2, P.global_w2, 256, nullptr, 0, P.global_b2, 0, 64);
+    eh_gemv_apply(Rg2, hid, nullptr, 0, 64, cn, 0);
     __syncthreads();
     // the parts of a graph are independent blocks: the old context is read from ctx_in and the new one goes
     // to the other copy (ctx), so a late part never sees a half-updated value
-    if (l >= P.num_layers) {
-        if ((TAIL || prt == 0) && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
-        return;
-    }
+    if (prt == 0 && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
+    if (!outputs) return;
+    load_last();
     const float* xc = (l > 0) ? cn : zero64;      // layer 0 sees x = h0 (no context added yet)
-    {   // qbias[o] = mbcat[o] + Mtcat[o,:] . te + Mcat[o,:] . ctx      share of this part
-        const int per = ((lp.H / 16 + EH_GU_PARTS - 1) / EH_GU_PARTS) * 16;
-        const int first = TAIL ? 0 : prt * per;
-        const int count = TAIL ? lp.H : (first + per <= lp.H ? per : (lp.H > first ? lp.H - first : 0));
-        eh_block_gemv<64, true, NW>(lp.Mtcat, 64, tev, lp.Mcat, 64, xc, lp.mbcat, first, count, qbias + (size_t)g * ldq, 0);
-    }
-    // cbias = context_b0 + context_w0[:, 64:128] . ctx (64 rows per part) and, on parts 1 and 2,
-    // obias0 = skip_b + skip_w[:, 64:128] . te + skip_w[:, :64] . ctx  /  obias1 = bvbar + Vbbar . te + Vsum . ctx:
-    // 64 outputs each, their weight rows requested together (one L2 round trip instead of two; same arithmetic)
+    // qbias[o] = mbcat[o] + Mtcat[o,:] . te + Mcat[o,:] . ctx      share of this part
+    eh_gemv_apply(Rq, tev, xc, qfirst, qcount, qbias + (size_t)g * ldq, 0);
     {
-        static_assert(256 / EH_GU_PARTS == 64, "four passes of 16 outputs per job");
-        static_assert(!TAIL || NW == 8, "the tail form deals the four parts to two groups of four waves");
-        const int lane = tid & 63, wave = (tid >> 6) & 3, sub = lane >> 4, kq = lane & 15;
+        float* oy = (prt == 1 ? obias0 : obias1) + (size_t)g * 64;
         const f32x4 xcn = *reinterpret_cast<const f32x4*>(cn + 4 * kq);
         const f32x4 xte = *reinterpret_cast<const f32x4*>(tev + 4 * kq);
         const f32x4 xx = *reinterpret_cast<const f32x4*>(xc + 4 * kq);
-        // TAIL: waves 0-3 take parts 0 and 2, waves 4-7 parts 1 and 3
-        for (int pr = TAIL ? (tid >> 8) : prt; pr < (TAIL ? EH_GU_PARTS : prt + 1); pr += TAIL ? 2 : 1) {
-            const bool two = pr == 1 || pr == 2;                          // wave-uniform
-            const float* Wt = pr == 1 ? lp.skip_w + 64 : lp.Vbbar;        // . te
-            const float* Wx = pr == 1 ? lp.skip_w : lp.Vsum;              // . ctx (layer 0: zeros)
-            const int ldo = pr == 1 ? 128 : 64;
-            const float* ob = pr == 1 ? lp.skip_b : lp.bvbar;
-            float* oy = (pr == 1 ? obias0 : obias1) + (size_t)g * 64;
-            f32x4 wc[4], wt[4], wx[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int o = 16 * p + 4 * wave + sub;
-                wc[p] = *reinterpret_cast<const f32x4*>(P.context_w0 + 64 + (size_t)(pr * 64 + o) * 128 + 4 * kq);
-                if (two) {
-                    wt[p] = *reinterpret_cast<const f32x4*>(Wt + (size_t)o * ldo + 4 * kq);
-                    wx[p] = *reinterpret_cast<const f32x4*>(Wx + (size_t)o * ldo + 4 * kq);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int o = 16 * p + 4 * wave + sub;
-                float sc = 0.f;
-                sc += wc[p][0] * xcn[0] + wc[p][1] * xcn[1] + wc[p][2] * xcn[2] + wc[p][3] * xcn[3];
-                sc = eh_row16_sum(sc);
-                if (kq == 0) cbias[(size_t)g * 256 + pr * 64 + o] = sc + P.context_b0[pr * 64 + o];
-                if (two) {
-                    float so = 0.f;
-                    so += wt[p][0] * xte[0] + wt[p][1] * xte[1] + wt[p][2] * xte[2] + wt[p][3] * xte[3];
-                    so += wx[p][0] * xx[0] + wx[p][1] * xx[1] + wx[p][2] * xx[2] + wx[p][3] * xx[3];
-                    so = eh_row16_sum(so);
-                    if (kq == 0) oy[o] = so + ob[o];
-                }
+        for (int p = 0; p < 4; ++p) {
+            const int o = 16 * p + 4 * wave + sub;
+            float sc = 0.f;
+            sc += wc[p][0] * xcn[0] + wc[p][1] * xcn[1] + wc[p][2] * xcn[2] + wc[p][3] * xcn[3];
+            sc = eh_row16_sum(sc);
+            if (kq == 0) cbias[(size_t)g * 256 + prt * 64 + o] = sc + bc[p];
+            if (two) {
+                float so = 0.f;
+                so += wt[p][0] * xte[0] + wt[p][1] * xte[1] + wt[p][2] * xte[2] + wt[p][3] * xte[3];
+                so += wx[p][0] * xx[0] + wx[p][1] * xx[1] + wx[p][2] * xx[2] + wx[p][3] * xx[3];
+                so = eh_row16_sum(so);
+                if (kq == 0) oy[o] = so + bo[p];
             }
         }
     }
-    if ((TAIL || prt == 0) && tid < 64) ctx[(size_t)g * 64 + tid] = cn[tid];
 }
 
 __global__ __launch_bounds__(256) void k_graph_update(edgehip_layout L, edgehip_gnn_params P, eh_update_args u) {
     __shared__ __attribute__((aligned(16))) float sm[768];
-    eh_graph_update_body<4, false>(sm, L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
+    eh_graph_update_body(sm, L, P, u.l, u.lp, u.part, u.te, u.t_graph, u.te_shared, u.ctx_in, u.ctx, u.qbias, u.ldq, u.obias0,
                          u.obias1, u.cbias, u.idle, u.ccount, blockIdx.x / EH_GU_PARTS, blockIdx.x % EH_GU_PARTS);
 }
 
