@@ -202,16 +202,20 @@ def make_model(n, edges, device, T=T_STEPS):
     return model, d
 
 
-def layer_work(rows):
+def layer_work(rows, head_visits=0.0):
     """Algorithmic flops / HBM bytes of ONE launch of the fused layer kernel over `rows` node rows (DESIGN.md
     'Kernels'), averaged over the 5 layers.  Flops are those of the FOLDED formulation the library executes (keys /
-    values never formed): q~ = h Mcat, conv = [z|h] Ocat, GRU (6 x 64x64), ctx 64->256."""
+    values never formed): q~ = h Mcat, conv = [z|h] Ocat, GRU (6 x 64x64), ctx 64->256 - the dense products - plus
+    the attention of ALL rows, which the kernel walks itself: per (target, neighbour, head) visit a 64-channel score
+    and a 64-channel weighted sum = 256 fp32 flops on the vector ALU (`head_visits` per launch, counted by the kernel).
+    Returns (all flops, bytes, dense-product flops)."""
     import numpy as np
-    fl = np.mean([2.0 * rows * (64 * 64 * h + (64 * h + 64) * 64 + 6 * 64 * 64 + 64 * 256) for h in HEADS])
+    dense = np.mean([2.0 * rows * (64 * 64 * h + (64 * h + 64) * 64 + 6 * 64 * 64 + 64 * 256) for h in HEADS])
+    fl = dense + 256.0 * head_visits
     # HBM: read h row + bit row (~160 B), write h' row + per-tile context sums; q~/z stay in LDS, neighbour rows
     # and weights are L2-resident re-reads
     by = rows * (256 + 160 + 256) + (rows / 32) * 1024
-    return fl, by
+    return fl, by, dense
 
 
 def train_flops(Nn, directed_edges, A):
@@ -377,16 +381,18 @@ def main():
         # of graphs overlap on several streams, and the duration of a launch that shares the chip with another
         # stream's launches is not a property of the kernel (`python bench.py --parts 1` times that end to end).
         import ctypes
-        rows_done = ctypes.c_ulonglong(0)
+        rows_done, visits_done = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
         stats = torch.zeros((T_STEPS, 8), dtype=torch.int64, device=device)
         torch.cuda.synchronize()
         capi.lib.edgehip_prof_enable(1)
         capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
+        capi.lib.edgehip_prof_layer_visits(ctypes.byref(visits_done), 1)
         t0 = time.perf_counter()
         model.sample_batch(batch, seed=1000 + a.steps - 1, parts=1, step_stats=stats)    # the last timed pass again
         torch.cuda.synchronize()
         one_stream_s = time.perf_counter() - t0
         capi.lib.edgehip_prof_layer_rows(ctypes.byref(rows_done), 1)
+        capi.lib.edgehip_prof_layer_visits(ctypes.byref(visits_done), 1)
         prof = capi.prof_collect()
         capi.lib.edgehip_prof_enable(0)
         tot = sum(v[0] for v in prof.values())
@@ -396,19 +402,27 @@ def main():
         roof = None
         if dom == 'layer':
             rows = rows_done.value / kern['layer']['launches']      # rows per launch really processed
-            fl, by = layer_work(rows)
+            hvis = visits_done.value / kern['layer']['launches']    # (target, neighbour, head) visits per launch
+            fl, by, dense = layer_work(rows, hvis)
             dur = kern[dom]['avg_us'] * 1e-6
             ach = fl / dur / 1e12
-            ex = BF16_PRODUCTS_PER_FP32 * ach
-            roof = {'kernel': 'k_layer<h> (fused GNN layer)', 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS,
+            ex = BF16_PRODUCTS_PER_FP32 * dense / dur / 1e12
+            roof = {'kernel': 'k_layer<h> (fused GNN layer: dense products on the matrix pipe + the attention of every row '
+                              'on the vector ALU)', 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
-                    # the fp32 products are EXECUTED as six bf16 MFMA products: the figure above prices the algorithmic
-                    # fp32 flops against the fp32 matrix peak, this one the executed bf16 flops against the bf16 peak
+                    'peak_note': 'fp32 peak of the chip, 157.3 TFLOP/s on the matrix pipe and the same on the vector ALU: the '
+                                 'kernel\'s algorithmic fp32 flops (dense products + attention) are priced against it',
+                    'dense_products_only': {'achieved': dense / dur / 1e12, 'frac': dense / dur / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                            'note': 'the figure of rounds 1-3 (attention not counted); until round 3 the rows '
+                                                    'above 48 neighbours were walked by a kernel of their own'},
+                    # the fp32 products are EXECUTED as six bf16 MFMA products: the figures above price algorithmic fp32
+                    # flops against the fp32 peak, this one the executed bf16 flops against the bf16 matrix peak
                     'executed': {'instruction': 'v_mfma_f32_32x32x16_bf16, 6 products per fp32 product', 'achieved': ex,
                                  'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / MFMA_BF16_PEAK_TFLOPS},
                     'measured': 'one extra pass, whole batch on one stream (kernel alone on the chip)',
-                    'avg_launch_us': kern[dom]['avg_us'], 'rows_per_launch': rows,
+                    'avg_launch_us': kern[dom]['avg_us'], 'rows_per_launch': rows, 'head_visits_per_launch': hvis,
                     'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
+                    'dense_flops_per_launch': dense, 'attention_flops_per_launch': fl - dense,
                     'hbm_frac_of_this_kernel': by / dur / 1e9 / HBM_PEAK_GBPS}
         res['roofline'] = roof
         res['kernels'] = kern

@@ -1084,12 +1084,15 @@ struct eh_layer_args {
 
 // node rows the fused layer kernel actually processed (idle graphs excluded) since the last read
 __device__ unsigned long long eh_layer_rows;
-extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) {
-    if (!out_host) return EDGEHIP_ERR_ARG;
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(eh_layer_rows), sizeof(unsigned long long)) != hipSuccess) return EDGEHIP_ERR_LAUNCH;
-    if (reset) { unsigned long long z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(eh_layer_rows), &z, sizeof(z)); }
+// (target, neighbour, head) score + weighted-sum visits of its attention phase since the last read
+__device__ unsigned long long eh_layer_visits;
+#define EH_READ_COUNTER(SYM)                                                                                                   \
+    if (!out_host) return EDGEHIP_ERR_ARG;                                                                                     \
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(SYM), sizeof(unsigned long long)) != hipSuccess) return EDGEHIP_ERR_LAUNCH;   \
+    if (reset) { unsigned long long z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(SYM), &z, sizeof(z)); }                          \
     return EDGEHIP_OK;
-}
+extern "C" int edgehip_prof_layer_rows(unsigned long long* out_host, int reset) { EH_READ_COUNTER(eh_layer_rows) }
+extern "C" int edgehip_prof_layer_visits(unsigned long long* out_host, int reset) { EH_READ_COUNTER(eh_layer_visits) }
 
 // Block barrier of the fused layer kernel.  Its waves only exchange data through LDS, so a barrier has to wait for the
 // LDS queue alone (s_waitcnt lgkmcnt(0)).  __syncthreads() is a workgroup fence + s_barrier, and for the fence hipcc
@@ -1227,6 +1230,12 @@ __global__ __launch_bounds__(512, 4) void k_layer(edgehip_layout L, eh_layer_arg
     if (tid < 32) { nl[tid] = mynid; wl[tid] = tid < rows ? a.cwgt[cbase + tid] : 0.f; }
     const int mydeg = a.deg[mynid];
     if (tid < 32) dl[tid] = mydeg;
+    if (a.count_rows && wave == 0) {                                       // measurement runs only
+        int dsum = lane < rows ? mydeg : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+        if (lane == 0) atomicAdd(&eh_layer_visits, (unsigned long long)dsum * HEADS);
+    }
 
     // ---- phase 0 loads: the h tile, one 16-byte piece per thread
     f32x4 h0v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)__shfl(mynid, (tid >> 4) & 31) * 64 + (tid & 15) * 4);

@@ -159,6 +159,8 @@ def _load():
     lib.edgehip_prof_num_kernels.restype = C.c_int32
     lib.edgehip_prof_layer_rows.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     lib.edgehip_prof_layer_rows.restype = C.c_int
+    lib.edgehip_prof_layer_visits.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    lib.edgehip_prof_layer_visits.restype = C.c_int
     return lib
 
 
@@ -177,7 +179,7 @@ def check(rc, what=''):
 MISC_EXPORTS = ('edgehip_edge_ce_loss_static_max_tiles', 'edgehip_train_set_side_stream', 'edgehip_layout_pair_tile_bound')
 MAX_PAIR_TILES = 1 << 29
 PROF_EXPORTS = ('edgehip_prof_enable', 'edgehip_prof_collect', 'edgehip_prof_kernel_name', 'edgehip_prof_num_kernels',
-                'edgehip_prof_layer_rows')
+                'edgehip_prof_layer_rows', 'edgehip_prof_layer_visits')
 
 
 def edgehip_static_tiles():

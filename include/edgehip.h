@@ -486,10 +486,14 @@ const char* edgehip_prof_kernel_name(int32_t id);
 /* node rows the fused layer kernel processed since the last reset (graphs without active pairs are skipped);
  * synchronises.  bench.py prices the roofline with the work that was executed, not the batch size. */
 int edgehip_prof_layer_rows(unsigned long long* out_host, int reset);
+/* (target, neighbour, head) visits of the same kernel's attention phase since the last reset: 256 fp32 flops each
+ * (64-channel score + 64-channel weighted sum); synchronises. */
+int edgehip_prof_layer_visits(unsigned long long* out_host, int reset);
 int32_t edgehip_prof_num_kernels(void);
 /* what the LAST edgehip_sample_step on workspace `ws` worked on; out_dev: int64[8] on the device =
  * {active nodes K, active pairs A, graphs with >= 2 active nodes (the rest were skipped), live node rows after the
- * isolated-class compaction, heavy rows, long rows, sum of degrees of the state the step started from (2 E_t),
+ * isolated-class compaction, rows of those graphs with more than 48 neighbours, rows walked by a whole tile together
+ * (more than 192), sum of degrees of the state the step started from (2 E_t),
  * nodes of the non-skipped graphs}.  Asynchronous on `stream`. */
 int edgehip_prof_step_stats(const edgehip_layout* L, const edgehip_gnn_params* P, void* ws, size_t ws_bytes,
                             const edgehip_counts* counts, int64_t* out_dev, void* stream);
