@@ -74,6 +74,18 @@ def test_one_layer_node_states_vs_oracle_on_a_wide_graph(heads):
                          spare=lambda n: (np.arange(n) % 10 == 0).astype(np.int64), min_active=2)
 
 
+@pytest.mark.parametrize('heads', [8, 1])
+def test_one_layer_node_states_vs_oracle_on_a_dense_graph(heads):
+    """300 nodes at density 0.85: every row has ~255 neighbours, more than EH_LONG_DEG - every row of every tile goes
+    through the joint walk of the eight waves (32 rounds of hand-over per tile).  Plus a sparse second graph with one
+    hub of 320 neighbours in the same launch."""
+    rng = np.random.default_rng(31)
+    dense = dict(n=300, edges=cases.random_graph(rng, 300, 0.85))
+    hub = dict(n=330, edges=np.array([(0, j) for j in range(1, 321)] + [(j, j + 1) for j in range(1, 300, 3)], dtype=np.int64))
+    _one_layer_vs_oracle([dense, hub], heads, False, rng, hubs=None,
+                         spare=lambda n: (np.arange(n) % 5 == 0).astype(np.int64), min_active=2)
+
+
 def _node_states(model, graph, d0, t, u):
     """h after the (one) layer for every node of one graph, through edgehip_gnn_forward."""
     import edgehip
