@@ -440,7 +440,7 @@ def main():
             'active_pairs_A': [int(st[i, 1]) for i in idx],
             'non_idle_graphs': [int(st[i, 2]) for i in idx],
             'live_rows': [int(st[i, 3]) for i in idx],
-            'heavy_rows': [int(st[i, 4]) for i in idx],
+            'rows_above_48_neighbours': [int(st[i, 4]) for i in idx],
             'total_pair_decisions': int(st[:, 1].sum()),
             'idle_graph_step_fraction': float(1.0 - st[:, 2].sum() / (B * T_STEPS)),
             'live_row_fraction_of_all_rows': float(st[:, 3].sum() / (nodes_all * T_STEPS)),

@@ -509,7 +509,7 @@ class BinomialDiffusionActive(nn.Module):
         """T fused reverse steps of a prepared batch (no host sync), then the edge-list epilogue.
         parts > 1: contiguous blocks of graphs run on separate HIP streams, their steps issued round-robin.
         Graphs do not interact and the uniforms are keyed by the global graph id, so the result is the same
-        bit for bit; but while one block sits in its latency-bound launches (per-graph update, heavy rows)
+        bit for bit; but while one block sits in its latency-bound launches (per-graph update, prepare, tail)
         another block's fused layer kernel fills the chip."""
         L, dev = batch.layout, batch.device
         net = self._denoise_fn
