@@ -63,12 +63,10 @@ def main():
     if hasattr(capi.lib, 'edgehip_debug_read'):
         buf = (C.c_ulonglong * 16)()
         capi.lib.edgehip_debug_read(buf, 1)
-        tot_c = sum(buf[:7]) or 1
-        names = ['0 load h', 'A qt', 'B attention', 'C conv mma', 'C reduce', 'D gru', 'E ctx']
-        print('  k_layer phase shares (wave 0 cycles):', ', '.join(f'{n} {100 * buf[i] / tot_c:.1f}%' for i, n in enumerate(names)))
-        sub = ['B.decode', 'B.q load', 'B.walk', 'B.z write']
-        print('  inside B (wave 0):', ', '.join(f'{n} {100 * buf[8 + i] / tot_c:.1f}%' for i, n in enumerate(sub)),
-              f'; barrier wait {100 * (buf[2] - sum(buf[8:12])) / tot_c:.1f}%')
+        tot_c = sum(buf[:9]) or 1
+        names = ['0 h planes', 'A qt', 'B stream walk (decode + visits)', 'B long rows', 'B zero + barrier wait', 'C conv products',
+                 'C reduce + silu', 'D gru', 'E ctx']
+        print('  k_layer phase shares (thread 0 of every tile, s_memtime):', ', '.join(f'{n} {100 * buf[i] / tot_c:.1f}%' for i, n in enumerate(names)))
 
 
 if __name__ == '__main__':
